@@ -1,0 +1,138 @@
+/* uob_rt.h — C ABI of the MI355X-native Cornell-Box ray tracer (libuob_rt.so).
+ *
+ * This library replaces ONE path of harrywaugh/UOB_Raytracer: the OpenCL device boundary of
+ * Source/skeleton.cpp — `opencl_initialise` (:366-497, build kernel + upload scene once) and
+ * `offload_rendering` (:146-182, per-frame args + clEnqueueNDRangeKernel(draw) + blocking readback) —
+ * and the kernel behind it, `draw` (Source/kernels.cl:368-428).  Plain pointers and sizes only; no C++
+ * or torch types cross this boundary.  A maintainer's binding is shown in INTEGRATION.md.
+ *
+ * Conventions: every function returns RT_OK (0) or a negative RT_E_* code; the message for the last
+ * failure on the calling thread is available from rt_last_error().  A context is not thread-safe
+ * (the reference has one host thread and one in-order queue, skeleton.cpp:388).
+ */
+#ifndef UOB_RT_H
+#define UOB_RT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1
+#define RT_MAX_SPHERES 4
+
+enum {
+  RT_OK = 0,
+  RT_E_INVALID = -1,  /* bad argument / configuration                                            */
+  RT_E_DEVICE = -2,   /* HIP runtime error (message carries hipGetErrorString)                   */
+  RT_E_NOMEM = -3,
+  RT_E_IO = -4,       /* file open/parse failure (OBJ loader, image writer)                      */
+  RT_E_UNSUPPORTED = -5
+};
+
+/* One analytic sphere: kernels.cl:7-10 (sphere_centers / sphere_colors / sphere_radius_sqs).
+ * color[3] is the material flag exactly like Triangle::color.w: >0 diffuse, 0 mirror, <0 glass.  */
+typedef struct rt_sphere {
+  float center[3];
+  float radius_sq;
+  float color[4];
+} rt_sphere;
+
+/* Every knob that the reference hard-codes as a #define/const (SURVEY.md §5 "Config / flags").
+ * rt_config_default() fills in the reference's shipped values.                                   */
+typedef struct rt_config {
+  int32_t width, height;        /* SCREEN_WIDTH / SCREEN_HEIGHT, kernels.cl:16-17, skeleton.cpp:32-33 */
+  int32_t aa_x, aa_y;           /* rays_x / rays_y, kernels.cl:12-13 (aa_rays = aa_x*aa_y)            */
+  int32_t shadow_samples;       /* light_sources, kernels.cl:316                                       */
+  float   light_spread;         /* kernels.cl:317                                                      */
+  int32_t max_bounces;          /* bounces, kernels.cl:343                                             */
+  int32_t num_spheres;          /* SPHERES, kernels.cl:7 (0..RT_MAX_SPHERES)                           */
+  rt_sphere spheres[RT_MAX_SPHERES];
+  /* Row-band partition of the frame for multi-GPU rendering: this context owns the rows y with
+   * (y / band_rows) % band_count == band_index, packed top to bottom in its output buffer.
+   * band_count = 1 renders the whole frame.  Ray directions and the per-pixel RNG seed always use the
+   * GLOBAL pixel coordinates (kernels.cl:378-380).                                                   */
+  int32_t band_rows, band_index, band_count;
+  int32_t device;               /* HIP device ordinal; -1 = current device                            */
+  int32_t flags;                /* RT_FLAG_*                                                           */
+} rt_config;
+
+#define RT_FLAG_FAST_MATH 1u    /* allow FMA contraction + v_rcp/v_rsq: NOT bit-exact */
+
+typedef struct rt_ctx rt_ctx;
+
+/* Per-frame work counters filled by rt_count_work (exact, reference early-exit semantics). */
+typedef struct rt_work {
+  uint64_t primary_rays, bounce_rays, shadow_rays;
+  uint64_t closest_tri_tests, closest_sphere_tests;   /* batch_/single_ray_intersections loops    */
+  uint64_t shadow_tri_tests, shadow_sphere_tests;     /* in_shadow loops incl. its early return   */
+  uint64_t lit_hits;                                  /* direct_light invocations                 */
+} rt_work;
+
+/* ---- configuration -------------------------------------------------------------------------- */
+/* Reference constants: 1024x1024, 2x2 AA, 10 shadow samples, spread 0.05, 10 bounces, the two live
+ * spheres of kernels.cl:8-10, whole frame on the current device.                                     */
+void rt_config_default(rt_config* cfg);
+/* Number of rows / pixels of the frame owned by cfg's band selection.                                */
+int32_t rt_config_owned_rows(const rt_config* cfg);
+
+/* ---- the device boundary (replaces skeleton.cpp:366-497 and :146-182) ----------------------- */
+/* Upload the scene once.  Arrays use the reference's packed layout (skeleton.cpp:474-484):
+ * vertices4 = float4[3n] (w ignored), normals4 = float4[n] (w ignored), colors4 = float4[n] with
+ * w = material flag.  The caller keeps ownership; data is copied before the call returns (as the
+ * CL_TRUE writes at skeleton.cpp:486-496 do).                                                        */
+int rt_init(const rt_config* cfg, const float* vertices4, const float* normals4, const float* colors4,
+            int32_t n_triangles, rt_ctx** out_ctx);
+
+/* Render one frame and read it back: rot = 3 rows x (x,y,z,pad) exactly as rot_matrix[12] at
+ * skeleton.cpp:149-151; cam/light = first 12 bytes of camera_position / light_position (:162,:164);
+ * focal = focal_length (:166), in units of AA sub-pixels along x.  out_argb receives
+ * owned_rows*width ARGB8888 words (A=255, kernels.cl:39); out_rgb_f32 (nullable) receives the
+ * pre-quantisation colour final/aa_rays as float4 (w=1) per pixel — the parity tap.  Synchronous,
+ * like the CL_TRUE read at skeleton.cpp:179.                                                         */
+int rt_render(rt_ctx* ctx, const float rot[12], const float cam[3], const float light[3], float focal,
+              uint32_t* out_argb, float* out_rgb_f32);
+
+/* Same frame, but the ARGB (and optional float4) output stays in device memory the caller owns
+ * (e.g. a torch tensor handed to an RCCL gather).  Enqueued on `hip_stream` (a hipStream_t, may be
+ * NULL for the default stream); returns without synchronising.                                       */
+int rt_render_device(rt_ctx* ctx, const float rot[12], const float cam[3], const float light[3],
+                     float focal, void* d_out_argb, void* d_out_rgb_f32, void* hip_stream);
+
+/* Exact work counters of the frame (un-timed instrumented pass; reference semantics).               */
+int rt_count_work(rt_ctx* ctx, const float rot[12], const float cam[3], const float light[3],
+                  float focal, rt_work* out);
+
+/* Device time of the most recent rt_render / rt_render_device kernel(s) on this context in ms,
+ * measured with hipEvents on the launch stream (synchronises that stream).                          */
+int rt_last_kernel_ms(rt_ctx* ctx, float* out_ms);
+
+void rt_destroy(rt_ctx* ctx);
+const char* rt_last_error(void);
+int rt_abi_version(void);
+
+/* ---- scene format (replaces TestModelH.h / Loader.cpp) -------------------------------------- */
+/* Triangle AoS exactly as TestModelH.h:14-18: 5 x vec4 = v0, v1, v2, normal, color (80 bytes).      */
+typedef struct rt_triangle {
+  float v0[4], v1[4], v2[4], normal[4], color[4];
+} rt_triangle;
+
+/* LoadTestModel (TestModelH.h:44-219): the 26-triangle Cornell Box.  Writes up to `cap` triangles,
+ * returns the triangle count (26) or a negative error.                                               */
+int rt_scene_cornell_box(rt_triangle* out, int32_t cap);
+/* load_obj (Loader.cpp:11-59): `v x y z` / `f a b c` lines, scale 1.5, negate, translate
+ * (-0.4,1.15,-0.7), colour blue (0,0.2,0.4,0.5); normals are those of the un-negated triangle.
+ * Returns the triangle count (may exceed cap; only cap are written) or a negative error.             */
+int rt_scene_load_obj(const char* path, rt_triangle* out, int32_t cap);
+/* ComputeNormal (TestModelH.h:26-35): normal = normalize(cross(v2-v0, v1-v0)), w = 1.               */
+void rt_triangle_compute_normal(rt_triangle* t);
+/* AoS -> the three packed float4 arrays (skeleton.cpp:474-484).                                      */
+void rt_scene_pack(const rt_triangle* tris, int32_t n, float* vertices4, float* normals4, float* colors4);
+/* Rotation matrix from yaw/pitch exactly as skeleton.cpp:149-151 (float cos/sin).                    */
+void rt_rotation_matrix(float yaw, float pitch, float rot[12]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UOB_RT_H */

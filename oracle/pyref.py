@@ -1,0 +1,217 @@
+"""TEST INFRASTRUCTURE ONLY — ctypes loaders for the checker libraries under oracle/.
+
+* `RefKernel(variant)`  : the real reference kernel built by oracle/build_ref.py (oracle/_ref/*.so)
+* `ref_scene()`         : the reference's own LoadTestModel / load_obj (oracle/_ref/libref_scene.so)
+* `Oracle()`            : the plain-C restatement oracle/rt_oracle.c (oracle/librt_oracle.so)
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
+product package (uob_raytracer_amd/) never does.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF_DIR = os.path.join(HERE, "_ref")
+
+FNV_OFFSET = 1469598103934665603
+FNV_PRIME = 1099511628211
+_M64 = (1 << 64) - 1
+
+
+def fnv1a64_bytes(buf):
+    """Byte-wise FNV-1a-64 (scene-buffer known answers)."""
+    h = FNV_OFFSET
+    for b in bytes(buf):
+        h = ((h ^ b) * FNV_PRIME) & _M64
+    return h
+
+
+def fnv1a64_words(words):
+    """FNV-1a-64 over uint32 words: hash ^= word; hash *= prime (framebuffer answers)."""
+    h = FNV_OFFSET
+    for w in np.asarray(words, dtype=np.uint32).ravel().tolist():
+        h = ((h ^ w) * FNV_PRIME) & _M64
+    return h
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def have_ref(variant="default"):
+    return os.path.exists(os.path.join(REF_DIR, "libref_%s.so" % variant))
+
+
+class RefKernel:
+    """The reference's `draw` kernel (kernels.cl:368) compiled for x86-64 with fixed constants."""
+
+    def __init__(self, variant="default"):
+        self.lib = C.CDLL(os.path.join(REF_DIR, "libref_%s.so" % variant))
+        self.W = self.lib.ref_width()
+        self.H = self.lib.ref_height()
+        self.lib.ref_render.argtypes = [C.POINTER(C.c_float)] * 3 + [C.c_int] + [C.POINTER(C.c_float)] * 3 + [
+            C.c_float, C.POINTER(C.c_uint32), C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_long, C.c_int]
+
+    def render(self, verts4, normals4, colors4, rot12, cam3, light3, focal, pix=None, nthreads=8, want_rgb=True):
+        v = np.ascontiguousarray(verts4, np.float32)
+        nr = np.ascontiguousarray(normals4, np.float32)
+        c = np.ascontiguousarray(colors4, np.float32)
+        n = c.size // 4
+        rot = np.ascontiguousarray(rot12, np.float32)
+        cam = np.ascontiguousarray(cam3, np.float32)
+        li = np.ascontiguousarray(light3, np.float32)
+        if pix is None:
+            npix, pp = self.W * self.H, None
+        else:
+            pix = np.ascontiguousarray(pix, np.int32)
+            npix, pp = pix.size, pix.ctypes.data_as(C.POINTER(C.c_int))
+        argb = np.zeros(npix, np.uint32)
+        rgb = np.zeros((npix, 3), np.float32) if want_rgb else None
+        self.lib.ref_render(_fp(v), _fp(nr), _fp(c), n, _fp(rot), _fp(cam), _fp(li), C.c_float(focal),
+                            argb.ctypes.data_as(C.POINTER(C.c_uint32)), _fp(rgb) if want_rgb else None,
+                            pp, npix, nthreads)
+        return argb, rgb
+
+    def in_shadow(self, verts4, colors4, rays, radius_sq):
+        v = np.ascontiguousarray(verts4, np.float32)
+        c = np.ascontiguousarray(colors4, np.float32)
+        rays = np.ascontiguousarray(rays, np.float32)
+        rs = np.ascontiguousarray(radius_sq, np.float32)
+        out = np.zeros(rs.size, np.uint8)
+        self.lib.ref_in_shadow(_fp(v), _fp(c), c.size // 4, _fp(rays), _fp(rs), C.c_long(rs.size),
+                               out.ctypes.data_as(C.POINTER(C.c_uint8)))
+        return out
+
+    def closest_hit(self, verts4, normals4, colors4, rays):
+        v = np.ascontiguousarray(verts4, np.float32)
+        nr = np.ascontiguousarray(normals4, np.float32)
+        c = np.ascontiguousarray(colors4, np.float32)
+        rays = np.ascontiguousarray(rays, np.float32)
+        k = rays.size // 6
+        tri = np.zeros(k, np.int32)
+        out = np.zeros((k, 10), np.float32)
+        self.lib.ref_closest_hit(_fp(v), _fp(nr), _fp(c), c.size // 4, _fp(rays), C.c_long(k),
+                                 tri.ctypes.data_as(C.POINTER(C.c_int)), _fp(out))
+        return tri, out
+
+
+def ref_scene():
+    lib = C.CDLL(os.path.join(REF_DIR, "libref_scene.so"))
+    return lib
+
+
+def ref_load_test_model():
+    """AoS [n,5,4] floats (v0,v1,v2,normal,color) from the reference's LoadTestModel (TestModelH.h:44)."""
+    lib = ref_scene()
+    buf = np.zeros((4096, 5, 4), np.float32)
+    n = lib.ref_load_test_model(_fp(buf), 4096)
+    return buf[:n].copy()
+
+
+def ref_load_obj(path, cap=400000):
+    lib = ref_scene()
+    buf = np.zeros((cap, 5, 4), np.float32)
+    n = lib.ref_load_obj(C.c_char_p(os.fsencode(path)), _fp(buf), cap)
+    return buf[:n].copy()
+
+
+def pack_scene(aos):
+    """skeleton.cpp:474-484: AoS -> float4 vertices[3n] (w=0), normals[n] (w=0), colors[n] (w=material)."""
+    aos = np.asarray(aos, np.float32)
+    n = aos.shape[0]
+    verts = np.zeros((n, 3, 4), np.float32)
+    verts[:, :, :3] = aos[:, 0:3, :3]
+    normals = np.zeros((n, 4), np.float32)
+    normals[:, :3] = aos[:, 3, :3]
+    colors = aos[:, 4, :].copy()
+    return verts.reshape(n * 3, 4), normals, colors
+
+
+def rot_matrix(yaw, pitch):
+    """skeleton.cpp:149-151, evaluated in float32 like the reference's float cos/sin."""
+    f = np.float32
+    cy, sy, cp, sp = f(np.cos(f(yaw))), f(np.sin(f(yaw))), f(np.cos(f(pitch))), f(np.sin(f(pitch)))
+    return np.array([cy, sp * sy, sy * cp, 0.0, 0.0, cp, -sp, 0.0, -sy, cy * sp, cp * cy, 0.0], np.float32)
+
+
+# --------------------------------------------------------------------------------------------------
+# plain-C restatement (oracle/rt_oracle.c)
+import sys as _sys
+
+_sys.path.insert(0, os.path.dirname(HERE))
+from uob_raytracer_amd import abi as _abi  # noqa: E402  (struct layouts only)
+
+
+def build_oracle():
+    import subprocess
+    subprocess.run(["make", "-s", "-C", HERE], check=True)
+
+
+class Oracle:
+    """oracle/rt_oracle.c — the configurable CPU restatement (strict IEEE, reference operation order)."""
+
+    def __init__(self):
+        path = os.path.join(HERE, "librt_oracle.so")
+        if not os.path.exists(path):
+            build_oracle()
+        self.lib = C.CDLL(path)
+        self.lib.rto_render.restype = C.c_int
+
+    def render(self, cfg, verts4, normals4, colors4, rot12, cam3, light3, focal, pix=None, nthreads=8,
+               want_work=False):
+        v = np.ascontiguousarray(verts4, np.float32)
+        nr = np.ascontiguousarray(normals4, np.float32)
+        c = np.ascontiguousarray(colors4, np.float32)
+        n = c.size // 4
+        rot = np.ascontiguousarray(rot12, np.float32)
+        cam = np.ascontiguousarray(cam3, np.float32)
+        li = np.ascontiguousarray(light3, np.float32)
+        if pix is None:
+            br = cfg.band_rows if cfg.band_rows > 0 else cfg.height
+            bc = max(cfg.band_count, 1)
+            rows = sum(1 for y in range(cfg.height) if (y // br) % bc == cfg.band_index)
+            npix, pp = rows * cfg.width, None
+        else:
+            pix = np.ascontiguousarray(pix, np.int32)
+            npix, pp = pix.size, pix.ctypes.data_as(C.POINTER(C.c_int))
+        argb = np.zeros(npix, np.uint32)
+        rgb = np.zeros((npix, 3), np.float32)
+        work = _abi.RtWork() if want_work else None
+        rc = self.lib.rto_render(C.byref(cfg), _fp(v), _fp(nr), _fp(c), n, _fp(rot), _fp(cam), _fp(li),
+                                 C.c_float(focal), argb.ctypes.data_as(C.POINTER(C.c_uint32)), _fp(rgb),
+                                 pp, C.c_long(npix), nthreads, C.byref(work) if want_work else None)
+        if rc != 0:
+            raise RuntimeError("rto_render failed: %d" % rc)
+        return (argb, rgb, work.as_dict()) if want_work else (argb, rgb)
+
+    def in_shadow(self, cfg, verts4, colors4, rays, radius_sq):
+        v = np.ascontiguousarray(verts4, np.float32)
+        c = np.ascontiguousarray(colors4, np.float32)
+        rays = np.ascontiguousarray(rays, np.float32)
+        rs = np.ascontiguousarray(radius_sq, np.float32)
+        out = np.zeros(rs.size, np.uint8)
+        self.lib.rto_in_shadow(C.byref(cfg), _fp(v), _fp(c), c.size // 4, _fp(rays), _fp(rs), C.c_long(rs.size),
+                               out.ctypes.data_as(C.POINTER(C.c_uint8)))
+        return out
+
+    def closest_hit(self, cfg, verts4, normals4, colors4, rays):
+        v = np.ascontiguousarray(verts4, np.float32)
+        nr = np.ascontiguousarray(normals4, np.float32)
+        c = np.ascontiguousarray(colors4, np.float32)
+        rays = np.ascontiguousarray(rays, np.float32)
+        k = rays.size // 6
+        tri = np.zeros(k, np.int32)
+        out = np.zeros((k, 10), np.float32)
+        self.lib.rto_closest_hit(C.byref(cfg), _fp(v), _fp(nr), _fp(c), c.size // 4, _fp(rays), C.c_long(k),
+                                 tri.ctypes.data_as(C.POINTER(C.c_int)), _fp(out))
+        return tri, out
+
+
+def quantise(rgb):
+    """color_pixel (kernels.cl:37-40) on float32 colours [..,3] -> ARGB words and the clamped 255*c tap."""
+    c = np.float32(255) * np.asarray(rgb, np.float32)
+    c = np.fmin(np.fmax(c, np.float32(0)), np.float32(255))
+    u = c.astype(np.uint32)
+    return (np.uint32(255) << 24) + (u[..., 0] << 16) + (u[..., 1] << 8) + u[..., 2], c
