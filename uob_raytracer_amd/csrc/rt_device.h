@@ -1,0 +1,44 @@
+// rt_device.h — structures shared by the host API (rt_api.hip) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/uob_rt.h"
+
+namespace uobrt {
+
+struct DevSphere {
+  float cx, cy, cz, r2;
+  float col[4];
+};
+
+// Everything one frame needs, passed by value as the kernel argument (lives in SGPRs / the scalar cache).
+struct FrameParams {
+  float rot[12];          // 3 rows x (x,y,z,pad), skeleton.cpp:149-151
+  float cam[3];
+  float focal;
+  float light[3];
+  float spread;           // light_spread, kernels.cl:317
+  int32_t W, H, aa_x, aa_y;
+  int32_t S;              // shadow samples
+  int32_t bounces;
+  int32_t nsph;
+  int32_t n;              // triangles
+  int32_t band_rows, band_index, band_count, owned_rows;
+  float sy;               // aa_x / aa_y: y sub-pixel pitch in x sub-pixel units (1 for square grids)
+  int32_t n_shadow;       // triangles that can cast a shadow (glass removed), for the wave kernel
+  DevSphere sph[RT_MAX_SPHERES];
+  const float4* verts;    // float4[3n]  (HBM, read once per workgroup while staging into LDS)
+  const float4* normals;  // float4[n]
+  const float4* colors;   // float4[n], w = material flag
+  uint32_t* out_argb;     // owned_rows * W ARGB8888 words
+  float4* out_rgb;        // nullable: owned_rows * W pre-quantisation colours
+  unsigned long long* counters;  // nullable: rt_work, 8 x u64
+};
+
+// Map a packed local row index to the global image row (band partition, include/uob_rt.h rt_config).
+__host__ __device__ inline int band_global_row(int lr, int band_rows, int band_index, int band_count) {
+  return ((lr / band_rows) * band_count + band_index) * band_rows + (lr % band_rows);
+}
+
+}  // namespace uobrt

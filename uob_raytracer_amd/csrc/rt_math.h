@@ -1,0 +1,51 @@
+// rt_math.h — scalar float3 helpers for the gfx950 kernels.
+//
+// Numerics contract: every translation unit that includes this header is compiled with
+// -ffp-contract=off and without fast-math, so each '*', '+', '-' below is ONE correctly rounded FP32
+// operation in the order written; '/' and sqrtf are correctly rounded (hipcc's default
+// -fhip-fp32-correctly-rounded-divide-sqrt).  The operation order follows the reference kernel
+// (Source/kernels.cl) so that results are bit-identical with the strict oracle.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace uobrt {
+
+struct f3 {
+  float x, y, z;
+};
+
+__device__ __forceinline__ f3 mk(float x, float y, float z) { return f3{x, y, z}; }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return f3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return f3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ f3 operator-(f3 a) { return f3{-a.x, -a.y, -a.z}; }
+__device__ __forceinline__ f3 operator*(float s, f3 a) { return f3{s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ f3 xyz(float4 v) { return f3{v.x, v.y, v.z}; }
+
+// OpenCL dot as the oracle defines it: x*x + y*y + z*z, left to right
+__device__ __forceinline__ float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// OpenCL normalize as the oracle defines it: v / sqrtf(dot(v,v))
+__device__ __forceinline__ f3 normalize3(f3 a) {
+  const float len = sqrtf(a.x * a.x + a.y * a.y + a.z * a.z);
+  return f3{a.x / len, a.y / len, a.z / len};
+}
+
+// The 2x2 cofactors of rows (m1, m2) used by det (kernels.cl:31-35):
+//   det(m0,m1,m2) = m0.x*c.x - m0.y*c.y + m0.z*c.z   with c = cof(m1,m2)
+__device__ __forceinline__ f3 cof(f3 m1, f3 m2) {
+  return f3{m1.y * m2.z - m1.z * m2.y, m1.x * m2.z - m1.z * m2.x, m1.x * m2.y - m1.y * m2.x};
+}
+__device__ __forceinline__ float detc(f3 m0, f3 c) { return m0.x * c.x - m0.y * c.y + m0.z * c.z; }
+
+// xorshift32 (kernels.cl:42-47), one component
+__device__ __forceinline__ uint32_t xorshift(uint32_t s) {
+  s ^= s << 13;
+  s ^= s >> 17;
+  s ^= s << 5;
+  return s;
+}
+// crush (kernels.cl:49-52), one component; (float)UINT_MAX rounds to 2^32
+__device__ __forceinline__ float crush1(uint32_t v, float range) {
+  return range * (float)v / 4294967296.0f - range / 2.f;
+}
+
+}  // namespace uobrt

@@ -1,0 +1,185 @@
+"""ctypes binding of libuob_rt.so (include/uob_rt.h) for tests and bench.py.
+
+The library is the product; this module is plumbing.  There is no CPU fallback: if the shared library
+cannot be loaded, or no HIP device is present when a context is created, the call raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libuob_rt.so")
+
+EXPORTS = (
+    "rt_abi_version", "rt_last_error", "rt_config_default", "rt_config_owned_rows", "rt_init", "rt_render",
+    "rt_render_device", "rt_count_work", "rt_last_kernel_ms", "rt_destroy", "rt_scene_cornell_box",
+    "rt_scene_load_obj", "rt_triangle_compute_normal", "rt_scene_pack", "rt_rotation_matrix",
+)
+
+_lib = None
+
+
+class RtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libuob_rt: error %d: %s" % (code, msg))
+        self.code = code
+
+
+def lib():
+    """Load libuob_rt.so (built by __graft_entry__.build() / make -C uob_raytracer_amd/csrc)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(there is no CPU fallback)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        fp, vp = C.POINTER(C.c_float), C.c_void_p
+        L.rt_last_error.restype = C.c_char_p
+        L.rt_config_default.argtypes = [C.POINTER(abi.RtConfig)]
+        L.rt_config_default.restype = None
+        L.rt_config_owned_rows.argtypes = [C.POINTER(abi.RtConfig)]
+        L.rt_init.argtypes = [C.POINTER(abi.RtConfig), fp, fp, fp, C.c_int32, C.POINTER(vp)]
+        L.rt_render.argtypes = [vp, fp, fp, fp, C.c_float, C.POINTER(C.c_uint32), fp]
+        L.rt_render_device.argtypes = [vp, fp, fp, fp, C.c_float, vp, vp, vp]
+        L.rt_count_work.argtypes = [vp, fp, fp, fp, C.c_float, C.POINTER(abi.RtWork)]
+        L.rt_last_kernel_ms.argtypes = [vp, fp]
+        L.rt_destroy.argtypes = [vp]
+        L.rt_destroy.restype = None
+        L.rt_scene_cornell_box.argtypes = [C.POINTER(abi.RtTriangle), C.c_int32]
+        L.rt_scene_load_obj.argtypes = [C.c_char_p, C.POINTER(abi.RtTriangle), C.c_int32]
+        L.rt_triangle_compute_normal.argtypes = [C.POINTER(abi.RtTriangle)]
+        L.rt_triangle_compute_normal.restype = None
+        L.rt_scene_pack.argtypes = [C.POINTER(abi.RtTriangle), C.c_int32, fp, fp, fp]
+        L.rt_scene_pack.restype = None
+        L.rt_rotation_matrix.argtypes = [C.c_float, C.c_float, fp]
+        L.rt_rotation_matrix.restype = None
+        if L.rt_abi_version() != abi.RT_ABI_VERSION:
+            raise ImportError("libuob_rt.so ABI %d != binding %d" % (L.rt_abi_version(), abi.RT_ABI_VERSION))
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc < 0:
+        raise RtError(rc, lib().rt_last_error().decode(errors="replace"))
+    return rc
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def default_config():
+    cfg = abi.RtConfig()
+    lib().rt_config_default(C.byref(cfg))
+    return cfg
+
+
+def rotation_matrix(yaw, pitch):
+    rot = np.zeros(12, np.float32)
+    lib().rt_rotation_matrix(C.c_float(yaw), C.c_float(pitch), _fp(rot))
+    return rot
+
+
+class Scene:
+    """Triangle list in the reference's AoS format (TestModelH.h:11-38): array [n,5,4] = v0,v1,v2,normal,color."""
+
+    def __init__(self, aos):
+        self.aos = np.ascontiguousarray(aos, np.float32).reshape(-1, 5, 4)
+
+    def __len__(self):
+        return self.aos.shape[0]
+
+    @classmethod
+    def cornell_box(cls):
+        """LoadTestModel (TestModelH.h:44)."""
+        buf = (abi.RtTriangle * 64)()
+        n = _check(lib().rt_scene_cornell_box(buf, 64))
+        return cls(np.frombuffer(buf, np.float32, n * 20).copy())
+
+    @classmethod
+    def load_obj(cls, path):
+        """load_obj (Loader.cpp:11)."""
+        n = _check(lib().rt_scene_load_obj(os.fsencode(path), None, 0))
+        buf = (abi.RtTriangle * max(n, 1))()
+        _check(lib().rt_scene_load_obj(os.fsencode(path), buf, n))
+        return cls(np.frombuffer(buf, np.float32, n * 20).copy())
+
+    def __add__(self, other):
+        """triangles.insert(end, ...) as at skeleton.cpp:103."""
+        return Scene(np.concatenate([self.aos, other.aos], axis=0))
+
+    def with_color(self, indices, rgba):
+        aos = self.aos.copy()
+        aos[list(indices), 4, :] = np.asarray(rgba, np.float32)
+        return Scene(aos)
+
+    def packed(self):
+        """The three float4 arrays uploaded at skeleton.cpp:474-496."""
+        n = len(self)
+        v = np.zeros((3 * max(n, 1), 4), np.float32)
+        nr = np.zeros((max(n, 1), 4), np.float32)
+        c = np.zeros((max(n, 1), 4), np.float32)
+        tris = self.aos.ctypes.data_as(C.POINTER(abi.RtTriangle))
+        lib().rt_scene_pack(tris, n, _fp(v), _fp(nr), _fp(c))
+        return v[:3 * n], nr[:n], c[:n]
+
+
+class RayTracer:
+    """One rt_ctx: the scene uploaded once (opencl_initialise), frames rendered on demand (offload_rendering)."""
+
+    def __init__(self, cfg, scene):
+        self.cfg = cfg
+        self.scene = scene
+        v, nr, c = scene.packed()
+        self._keep = (v, nr, c)
+        h = C.c_void_p()
+        _check(lib().rt_init(C.byref(cfg), _fp(v), _fp(nr), _fp(c), len(scene), C.byref(h)))
+        self._h = h
+        self.width = cfg.width
+        self.rows = lib().rt_config_owned_rows(C.byref(cfg))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().rt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _args(rot, cam, light):
+        return (np.ascontiguousarray(rot, np.float32), np.ascontiguousarray(cam, np.float32)[:3].copy(),
+                np.ascontiguousarray(light, np.float32)[:3].copy())
+
+    def render(self, rot, cam, light, focal, want_rgb=False):
+        """Blocking render + readback.  Returns ARGB [rows,W] (and the float4 tap [rows,W,4])."""
+        rot, cam, light = self._args(rot, cam, light)
+        argb = np.zeros((self.rows, self.width), np.uint32)
+        rgb = np.zeros((self.rows, self.width, 4), np.float32) if want_rgb else None
+        _check(lib().rt_render(self._h, _fp(rot), _fp(cam), _fp(light), C.c_float(focal),
+                               argb.ctypes.data_as(C.POINTER(C.c_uint32)), _fp(rgb) if want_rgb else None))
+        return (argb, rgb) if want_rgb else argb
+
+    def render_device(self, rot, cam, light, focal, d_argb_ptr, d_rgb_ptr=None, stream=None):
+        """Enqueue a frame into caller-owned device memory (raw pointers, e.g. torch .data_ptr())."""
+        rot, cam, light = self._args(rot, cam, light)
+        _check(lib().rt_render_device(self._h, _fp(rot), _fp(cam), _fp(light), C.c_float(focal),
+                                      C.c_void_p(d_argb_ptr), C.c_void_p(d_rgb_ptr or 0), C.c_void_p(stream or 0)))
+
+    def count_work(self, rot, cam, light, focal):
+        rot, cam, light = self._args(rot, cam, light)
+        w = abi.RtWork()
+        _check(lib().rt_count_work(self._h, _fp(rot), _fp(cam), _fp(light), C.c_float(focal), C.byref(w)))
+        return w.as_dict()
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        _check(lib().rt_last_kernel_ms(self._h, C.byref(ms)))
+        return float(ms.value)
