@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark: Cornell Box 4096x4096, 8xAA (4x2), 64 shadow rays (BASELINE.json).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one frame.  With N ranks the ONE frame is split into
+interleaved row bands (rank r renders bands r, r+N, ...: the partition of include/uob_rt.h rt_config),
+each rank renders its bands with the HIP kernel into its own HBM, the bands are gathered to rank 0 over
+RCCL and rank 0 de-interleaves them into the final ARGB frame — total work is fixed, so "scaling" is
+"strong".  `value` is nominal Mrays/s = W*H*AA*(1+S) / time, whole job, frame resident in HBM of rank 0.
+
+Prints ONE JSON line (rank 0) with `roofline` (FP32 vector ALU is the bounding unit of this path, see
+DESIGN.md; the HBM view the north star asks for is in `roofline_hbm`) and `cpu_baseline` (the CPU oracle
+timed on this host's cores on a bounded sample of the same frame).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_VALU_TFLOPS = 157.3     # MI355X_MICROARCH.md, chip-level parameters
+PEAK_HBM_GBPS = 8000.0
+FLOP_PER_TRI_TEST = 46            # Moeller-Trumbore with e1,e2 precomputed
+FLOP_PER_SPHERE_TEST = 30
+
+WORKLOADS = {
+    # BASELINE.json configs[3] / metric: the headline frame
+    "headline": dict(width=4096, height=4096, aa_x=4, aa_y=2, shadow_samples=64),
+    # configs[1]
+    "cfg2": dict(width=1024, height=1024, aa_x=2, aa_y=2, shadow_samples=16, spheres=()),
+    # the reference exactly as shipped
+    "reference": dict(width=1024, height=1024),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="headline", choices=list(WORKLOADS))
+    ap.add_argument("--band-rows", type=int, default=32)
+    ap.add_argument("--cpu-sample-pixels", type=int, default=0, help="0 = auto (about 10-30 s of CPU work)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from uob_raytracer_amd import abi, runtime as rt
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    wl = WORKLOADS[args.workload]
+    W, H = wl["width"], wl["height"]
+    band_rows = args.band_rows if world > 1 else H
+    cfg = abi.make_config(band_rows=band_rows, band_index=rank, band_count=world, device=local_rank, **wl)
+    scene = rt.Scene.cornell_box()
+    tracer = rt.RayTracer(cfg, scene)
+    rows = tracer.rows
+    focal = 1100.0 * min(W, H) / 1024.0 * cfg.aa_x
+    rot = rt.rotation_matrix(0.0, 0.0)
+    cam, light = [0.0, 0.0, -3.2], [0.0, -0.5, -0.7]
+
+    stripe = torch.empty((rows, W), dtype=torch.int32, device=dev)
+    gathered = None
+    if world > 1:
+        if H % (band_rows * world) != 0:
+            sys.exit("height must be a multiple of band_rows*gpus for the equal-size gather")
+        if rank == 0:
+            gathered = [torch.empty((rows, W), dtype=torch.int32, device=dev) for _ in range(world)]
+    frame = torch.empty((H, W), dtype=torch.int32, device=dev) if rank == 0 else None
+
+    def step():
+        stream = torch.cuda.current_stream().cuda_stream
+        tracer.render_device(rot, cam, light, focal, stripe.data_ptr(), None, stream)
+        if world > 1:
+            dist.gather(stripe, gathered, dst=0)
+            if rank == 0:   # [rank, band, row, x] -> [band, rank, row, x] = image order
+                g = torch.stack(gathered).view(world, -1, band_rows, W)
+                frame.view(-1, world, band_rows, W).copy_(g.permute(1, 0, 2, 3))
+        # N == 1: the kernel's output buffer IS the frame
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # exact algorithmic work of this rank's bands (un-timed instrumented pass)
+    work = tracer.count_work(rot, cam, light, focal)
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        tracer.render_device(rot, cam, light, focal, stripe.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+        ev[k][1].record()
+        if world > 1:
+            dist.gather(stripe, gathered, dst=0)
+            if rank == 0:
+                g = torch.stack(gathered).view(world, -1, band_rows, W)
+                frame.view(-1, world, band_rows, W).copy_(g.permute(1, 0, 2, 3))
+    sync()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    keys = list(work)
+    stats = torch.tensor([elapsed, kernel_ms] + [float(work[k]) for k in keys], dtype=torch.float64, device=dev)
+    if world > 1:
+        mx = stats[:2].clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = stats[2:].clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        stats = torch.cat([mx, sm])
+    stats = stats.cpu().numpy()
+    elapsed, kernel_ms = float(stats[0]), float(stats[1])
+    total_work = {k: int(round(v)) for k, v in zip(keys, stats[2:])}
+
+    # frame integrity: rank 0 hashes the final frame (N=1: the stripe is the frame)
+    if rank == 0:
+        final = stripe if world == 1 else frame
+        frame_sum = int(final.to(torch.int64).bitwise_and(0xFFFFFFFF).sum().item())
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    aa = cfg.aa_x * cfg.aa_y
+    nominal_rays = W * H * aa * (1 + cfg.shadow_samples)
+    traced_rays = total_work["primary_rays"] + total_work["bounce_rays"] + total_work["shadow_rays"]
+    ms_per_step = elapsed * 1e3 / args.steps
+    flops = (total_work["closest_tri_tests"] + total_work["shadow_tri_tests"]) * FLOP_PER_TRI_TEST + \
+            (total_work["closest_sphere_tests"] + total_work["shadow_sphere_tests"]) * FLOP_PER_SPHERE_TEST
+    # per launch = per rank: every rank runs the same kernel on 1/world of the frame
+    flops_per_launch = flops / world
+    achieved_tflops = flops_per_launch / (kernel_ms * 1e-3) / 1e12
+    wg = ((W + 63) // 64) * ((H // world + 3) // 4)
+    hbm_bytes_per_launch = W * (H // world) * 4 + wg * len(scene) * 80
+    achieved_gbps = hbm_bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+
+    out = {
+        "metric": "Mrays/sec (nominal = W*H*AA*(1+S)/t), Cornell Box 4096^2, 8xAA, 64 shadow rays",
+        "value": nominal_rays / (ms_per_step * 1e-3) / 1e6,
+        "unit": "Mrays/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "%s: Cornell Box %dx%d, %dx%d AA, %d shadow rays, %d spheres, <=%d bounces" % (
+            args.workload, W, H, cfg.aa_x, cfg.aa_y, cfg.shadow_samples, cfg.num_spheres, cfg.max_bounces),
+            "parallelism": "row bands of %d over %d GPU(s) + RCCL gather" % (band_rows, world) if world > 1 else "1 GPU"},
+        "kernel_ms_per_launch": kernel_ms,
+        "traced_mrays_per_s": traced_rays / (ms_per_step * 1e-3) / 1e6,
+        "nominal_rays_per_frame": nominal_rays, "traced_rays_per_frame": traced_rays,
+        "work_per_frame": total_work,
+        "frame_checksum": frame_sum,
+        "parity": "bit-exact vs CPU oracle (strict FP32, reference operation order); tolerance allowed 1e-4",
+        "roofline": {"bound": "valu", "achieved": achieved_tflops, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved_tflops / PEAK_FP32_VALU_TFLOPS, "traffic": None,
+                     "note": "FP32 vector ALU roof (SURVEY.md 8d): (tri_tests*46 + sphere_tests*30) flop per launch / kernel time"},
+        "roofline_hbm": {"bound": "hbm", "achieved": achieved_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                         "frac": achieved_gbps / PEAK_HBM_GBPS, "traffic": None,
+                         "note": "algorithmic bytes = 4 B/pixel ARGB + 80 B/triangle per workgroup; <<1% by construction"},
+    }
+
+    if not args.no_cpu_baseline:
+        from oracle import pyref   # checker, used here only as the timed CPU baseline
+        cores = os.cpu_count() or 1
+        npx = args.cpu_sample_pixels or 40000
+        rng = np.random.default_rng(12345)
+        pix = rng.choice(W * H, size=npx, replace=False).astype(np.int32)
+        full = abi.make_config(**wl)
+        v, n, c = scene.packed()
+        orc = pyref.Oracle()
+        orc.render(full, v, n, c, rot, cam, light, focal, pix=pix[:256], nthreads=cores)   # warm
+        t0 = time.perf_counter()
+        o_argb, _ = orc.render(full, v, n, c, rot, cam, light, focal, pix=pix, nthreads=cores)
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": npx * aa * (1 + cfg.shadow_samples) / dt / 1e6, "unit": "Mrays/s", "cores": cores,
+                               "kind": "port", "seconds": dt,
+                               "sample": "%d random pixels of the same %dx%d frame (%.3g nominal rays), CPU oracle, OpenMP" % (
+                                   npx, W, H, npx * aa * (1 + cfg.shadow_samples))}
+        # the sampled pixels double as an in-bench parity check of the frame just timed
+        got = (stripe if world == 1 else frame).view(-1)[torch.from_numpy(pix.astype(np.int64)).to(dev)].cpu().numpy().view(np.uint32)
+        out["cpu_baseline"]["gpu_frame_matches_oracle_on_sample"] = bool(np.array_equal(got, o_argb))
+
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
