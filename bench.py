@@ -189,8 +189,9 @@ def main():
 
     if not args.no_cpu_baseline:
         from oracle import pyref   # checker, used here only as the timed CPU baseline
-        cores = os.cpu_count() or 1
-        npx = args.cpu_sample_pixels or 40000
+        # the GPU box gives one-GPU jobs a 16-core share: never use more host threads than that
+        cores = min(len(os.sched_getaffinity(0)), 16)
+        npx = args.cpu_sample_pixels or 60000
         rng = np.random.default_rng(12345)
         pix = rng.choice(W * H, size=npx, replace=False).astype(np.int32)
         full = abi.make_config(**wl)

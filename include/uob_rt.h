@@ -59,6 +59,7 @@ typedef struct rt_config {
 } rt_config;
 
 #define RT_FLAG_FAST_MATH 1u    /* allow FMA contraction + v_rcp/v_rsq: NOT bit-exact */
+#define RT_FLAG_GENERIC_KERNEL 2u   /* always use the one-thread-per-pixel kernel (A/B and parity tests)  */
 
 typedef struct rt_ctx rt_ctx;
 

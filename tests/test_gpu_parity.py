@@ -20,6 +20,13 @@ CASES = {
     "s64_aa4x2_192": dict(width=192, height=192, aa_x=4, aa_y=2, shadow_samples=64),
     "aa3x3": dict(width=128, height=128, aa_x=3, aa_y=3),
     "ragged_100x37": dict(width=100, height=37, shadow_samples=4),
+    # 64 shadow samples: the wave-per-surface-point kernel (rt_kernel_wave.hip)
+    "wave_s64_aa2x2_160": dict(width=160, height=160, shadow_samples=64),
+    "wave_s64_aa1_128_nospheres": dict(width=128, height=128, aa_x=1, aa_y=1, shadow_samples=64, spheres=()),
+    "wave_s64_aa8x8_48": dict(width=48, height=48, aa_x=8, aa_y=8, shadow_samples=64),
+    "wave_s64_aa4x2_ragged_100x37": dict(width=100, height=37, aa_x=4, aa_y=2, shadow_samples=64),
+    "wave_s64_hard_shadow": dict(width=128, height=128, aa_x=2, aa_y=1, shadow_samples=64, light_spread=0.0),
+    "wave_s64_bands": dict(width=128, height=120, aa_x=4, aa_y=2, shadow_samples=64, band_rows=8, band_index=1, band_count=3),
 }
 
 

@@ -115,8 +115,8 @@ int rt_init(const rt_config* cfg, const float* vertices4, const float* normals4,
   if (rc != RT_OK) return rc;
   if (n < 0 || (n > 0 && (!vertices4 || !normals4 || !colors4))) { set_error("scene arrays missing"); return RT_E_INVALID; }
   if (cfg->flags & RT_FLAG_FAST_MATH) { set_error("RT_FLAG_FAST_MATH is not built into this library"); return RT_E_UNSUPPORTED; }
-  if ((size_t)n * 6 * sizeof(float4) > 160 * 1024) {
-    set_error("triangle list of %d does not fit one LDS stage (max %d); tiled staging is not available yet", n, (int)(160 * 1024 / 96));
+  if ((size_t)n * 8 * sizeof(float4) > 64 * 1024) {
+    set_error("triangle list of %d does not fit one LDS stage (max %d); tiled staging is not available yet", n, (int)(64 * 1024 / 128));
     return RT_E_UNSUPPORTED;
   }
   int ndev = 0;
@@ -185,7 +185,7 @@ static int launch_frame(rt_ctx* c, const float rot[12], const float cam[3], cons
   P.out_argb = d_argb; P.out_rgb = d_rgb; P.counters = nullptr;
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipEventRecord(c->ev0, stream));
-  if (wave_kernel_supports(P)) launch_wave(P, stream);
+  if (!(c->cfg.flags & RT_FLAG_GENERIC_KERNEL) && wave_kernel_supports(P)) launch_wave(P, stream);
   else launch_generic(P, false, stream);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(c->ev1, stream));

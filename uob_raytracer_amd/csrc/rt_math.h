@@ -36,6 +36,29 @@ __device__ __forceinline__ f3 cof(f3 m1, f3 m2) {
 }
 __device__ __forceinline__ float detc(f3 m0, f3 c) { return m0.x * c.x - m0.y * c.y + m0.z * c.z; }
 
+// native_recip of the strict oracle: the correctly rounded 1/x.
+//   RT_RCP_MODE 0: IEEE division (hipcc's correctly rounded expansion, ~11 VALU instructions)
+//   RT_RCP_MODE 1/2: v_rcp_f32 (1 ulp) refined by 1/2 Newton steps in FMA arithmetic — correctly rounded
+//   for every normal x except the inputs listed in DESIGN.md, which rt_selftest_rcp enumerates on the GPU.
+#ifndef RT_RCP_MODE
+#define RT_RCP_MODE 0
+#endif
+__device__ __forceinline__ float rcp_newton(float x, int steps) {
+  float r = __builtin_amdgcn_rcpf(x);
+  for (int k = 0; k < steps; ++k) {
+    const float e = __builtin_fmaf(-x, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+  }
+  return r;
+}
+__device__ __forceinline__ float rcp_strict(float x) {
+#if RT_RCP_MODE == 0
+  return 1.0f / x;
+#else
+  return rcp_newton(x, RT_RCP_MODE);
+#endif
+}
+
 // xorshift32 (kernels.cl:42-47), one component
 __device__ __forceinline__ uint32_t xorshift(uint32_t s) {
   s ^= s << 13;
