@@ -109,6 +109,12 @@ int rt_count_work(rt_ctx* ctx, const float rot[12], const float cam[3], const fl
  * measured with hipEvents on the launch stream (synchronises that stream).                          */
 int rt_last_kernel_ms(rt_ctx* ctx, float* out_ms);
 
+/* On-device self test of the exact-reciprocal building block (rt_math.h rcp_newton): sweeps all 2^32
+ * FP32 patterns and compares v_rcp_f32 + 1/2 Newton steps with the correctly rounded 1.0f/x.
+ * out[0],out[1] = mismatches (1-step, 2-step) for 2^-100 <= |x| <= 2^100; out[2],out[3] = mismatches for
+ * the remaining finite non-zero x; out[4] = examples recorded; out[8..63] = mismatching bit patterns.   */
+int rt_selftest_rcp(uint64_t out[64]);
+
 void rt_destroy(rt_ctx* ctx);
 const char* rt_last_error(void);
 int rt_abi_version(void);

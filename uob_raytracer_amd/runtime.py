@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libuob_rt.so")
 EXPORTS = (
     "rt_abi_version", "rt_last_error", "rt_config_default", "rt_config_owned_rows", "rt_init", "rt_render",
     "rt_render_device", "rt_count_work", "rt_last_kernel_ms", "rt_destroy", "rt_scene_cornell_box",
-    "rt_scene_load_obj", "rt_triangle_compute_normal", "rt_scene_pack", "rt_rotation_matrix",
+    "rt_scene_load_obj", "rt_triangle_compute_normal", "rt_scene_pack", "rt_rotation_matrix", "rt_selftest_rcp",
 )
 
 _lib = None
@@ -70,6 +70,15 @@ def _check(rc):
 
 def _fp(a):
     return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def selftest_rcp():
+    """All-2^32-patterns check of the exact reciprocal (include/uob_rt.h rt_selftest_rcp)."""
+    out = (C.c_uint64 * 64)()
+    _check(lib().rt_selftest_rcp(out))
+    v = list(out)
+    return {"safe_mismatch_1step": v[0], "safe_mismatch_2step": v[1], "edge_mismatch_1step": v[2],
+            "edge_mismatch_2step": v[3], "examples": [int(b) & 0xFFFFFFFF for b in v[8:8 + min(v[4], 56)]]}
 
 
 def default_config():
