@@ -43,38 +43,75 @@ struct TriLane {
   f3 v0, e1, e2, c;
 };
 
-// Number of the 64 jittered shadow rays (lane = sample) from `start` towards light that are NOT
+// Per-wave LDS records through which the triangle lanes hand their per-surface-point terms to the 64
+// sample lanes: every sample lane reads the SAME record, which LDS serves as a broadcast into VGPRs.
+// (Broadcasting through SGPRs instead — v_readlane_b32 — costs 4.3 issue cycles per value and makes
+// every VALU instruction that consumes the SGPR half rate: profiles/r01_valu_issue_cost_8waves.txt.)
+struct WaveRecs {
+  float4* r0;   // c.x c.y c.z | det(A0) = det(b,e1,e2)
+  float4* r1;   // p.x p.y p.z | q.x        p = cof(b,e2), q = cof(e1,b)
+  float2* r2;   // q.y q.z
+};
+constexpr int kWaveRecBytes = 64 * (16 + 16 + 8);
+constexpr int kWaveLdsBytes = kWaveRecBytes + kRngPixels * kRngStride * 4;
+
+__device__ __forceinline__ unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
+// Number of the 64 jittered shadow rays (lane = sample) from `start` towards the light that are NOT
 // blocked: kernels.cl:243-311 evaluated for 64 samples at once.  start/dir/radius_sq are wave-uniform.
-__device__ __forceinline__ int wave_unshadowed(const FrameParams& P, const TriLane& T, int ns, f3 start, f3 dir,
-                                               float radius_sq, f3 jit) {
+__device__ __forceinline__ int wave_unshadowed(const FrameParams& P, const TriLane& T, const WaveRecs& R, int lane,
+                                               int ns, f3 start, f3 dir, float radius_sq, f3 jit) {
   const f3 d = dir + jit;       // shadow_ray.direction + crush(rand_vec, light_spread), :333
   const f3 nd = -d;
   // ---- once per surface point, lane i = triangle i -------------------------------------------------
-  const f3 b = start - T.v0;
-  const float nA0 = detc(b, T.c);        // det(A0), :257-259
-  const f3 p = cof(b, T.e2);             // cofactors of det(A1) = det(-d, b, e2), :269
-  const f3 q = cof(T.e1, b);             // cofactors of det(A2) = det(-d, e1, b), :270
-  // ---- 64 samples against triangle i ----------------------------------------------------------------
-  bool sh = false;
-  for (int i = 0; i < ns; ++i) {
-    const f3 ci = rl3(T.c, i);
-    const float detA_recip = rcp_strict(detc(nd, ci));
-    const float t = rl(nA0, i) * detA_recip;
-    const f3 dv = t * d;
-    const float dist = dv.x * dv.x + dv.y * dv.y + dv.z * dv.z;
-    const bool pass = (t >= 0 && dist < radius_sq);                 // :266
-    if (__ballot(pass && !sh) != 0ull) {                            // wave-uniform second stage
-      const float u = detc(nd, rl3(p, i)) * detA_recip;
-      const float v = detc(nd, rl3(q, i)) * detA_recip;
-      sh = sh || (pass && u >= 0 && v >= 0 && (u + v) <= 1);        // :272
-      if (__ballot(!sh) == 0ull) break;                             // every sample blocked: any-hit early-out
-    }
+  {
+    const f3 b = start - T.v0;
+    const f3 p = cof(b, T.e2);             // cofactors of det(A1) = det(-d, b, e2), :269
+    const f3 q = cof(T.e1, b);             // cofactors of det(A2) = det(-d, e1, b), :270
+    reinterpret_cast<float*>(&R.r0[lane])[3] = detc(b, T.c);     // det(A0), :257-259
+    R.r1[lane] = make_float4(p.x, p.y, p.z, q.x);
+    R.r2[lane] = make_float2(q.y, q.z);
   }
-  if (P.nsph > 0 && __ballot(!sh) != 0ull) {
+  __builtin_amdgcn_wave_barrier();
+  // ---- 64 samples against triangle i ----------------------------------------------------------------
+  // Lane predicates are kept as explicit 64-bit wave masks: each ballot below is ONE v_cmp writing an
+  // SGPR pair, and all the and/or logic runs on the scalar unit.
+  unsigned long long shadowed = 0ull;
+  float4 r0 = R.r0[0];
+  for (int i = 0; i < ns; ++i) {
+    const float4 nxt = R.r0[i + 1];          // prefetch the next record (slot ns <= 63 is valid memory)
+    const float detA = detc(nd, mk(r0.x, r0.y, r0.z));
+    float rr = rcp_newton(detA, 1);          // == 1.0f/detA, or NaN when detA is 0/denormal/inf (rt_math.h)
+    float t = r0.w * rr;
+    f3 dv = t * d;
+    float dist = dv.x * dv.x + dv.y * dv.y + dv.z * dv.z;
+    // first stage, :266.  The negated compares are also true for NaN, so a lane whose reciprocal needs
+    // the division fallback reaches the second stage, where it is recomputed exactly.
+    unsigned long long pass = ballot(!(t < 0.0f)) & ballot(!(dist >= radius_sq));
+    if ((pass & ~shadowed) != 0ull) {                                // wave-uniform second stage
+      if (ballot(rr != rr) != 0ull) {                                // rare: reciprocal outside v_rcp's range
+        rr = 1.0f / detA;
+        t = r0.w * rr;
+        dv = t * d;
+        dist = dv.x * dv.x + dv.y * dv.y + dv.z * dv.z;
+        pass = ballot(t >= 0) & ballot(dist < radius_sq);
+      }
+      const float4 r1 = R.r1[i];
+      const float2 r2 = R.r2[i];
+      const float u = detc(nd, mk(r1.x, r1.y, r1.z)) * rr;
+      const float v = detc(nd, mk(r1.w, r2.x, r2.y)) * rr;
+      shadowed |= pass & ballot(u >= 0) & ballot(v >= 0) & ballot((u + v) <= 1);   // :272
+      if (shadowed == ~0ull) break;                                  // every sample blocked: any-hit early-out
+    }
+    r0 = nxt;
+  }
+  __builtin_amdgcn_wave_barrier();
+  bool sh = (shadowed >> lane) & 1ull;
+  if (P.nsph > 0 && shadowed != ~0ull) {
     Work wk;
     if (!sh) sh = shadow_spheres<false>(P, start, d, radius_sq, wk);
   }
-  return __popcll(__ballot(!sh));
+  return __popcll(ballot(!sh));
 }
 
 }  // namespace
@@ -95,7 +132,10 @@ __global__ __launch_bounds__(256) void rt_draw_wave(const FrameParams P) {
     if (casts) sidx[__popcll(m & ((1ull << lane) - 1ull))] = lane;
   }
   __syncthreads();
-  uint32_t* rng = reinterpret_cast<uint32_t*>(sidx + ((n + 3) & ~3)) + wave * (kRngPixels * kRngStride);
+  char* wave_lds = reinterpret_cast<char*>(sidx + ((n + 3) & ~3)) + wave * kWaveLdsBytes;
+  const WaveRecs R{reinterpret_cast<float4*>(wave_lds), reinterpret_cast<float4*>(wave_lds + 64 * 16),
+                   reinterpret_cast<float2*>(wave_lds + 64 * 32)};
+  uint32_t* rng = reinterpret_cast<uint32_t*>(wave_lds + kWaveRecBytes);
 
   const int lr = blockIdx.y * 4 + wave;
   if (lr >= P.owned_rows) return;                                     // whole wave; no block barrier follows
@@ -112,6 +152,7 @@ __global__ __launch_bounds__(256) void rt_draw_wave(const FrameParams P) {
   {
     const int ti = sidx[lane < ns ? lane : 0];
     T.v0 = xyz(S.v0[ti]); T.e1 = xyz(S.e1[ti]); T.e2 = xyz(S.e2[ti]); T.c = xyz(S.c[ti]);
+    R.r0[lane] = make_float4(T.c.x, T.c.y, T.c.z, 0.f);       // static part of record 0
   }
 
   f3 outc = mk(0.f, 0.f, 0.f);
@@ -140,7 +181,7 @@ __global__ __launch_bounds__(256) void rt_draw_wave(const FrameParams P) {
 
     // ---- phase 3: wave-wide shadow test, one lit lane at a time ---------------------------------------
     int unshadowed = 0;
-    const unsigned long long litmask = __ballot(lit);
+    const unsigned long long litmask = ballot(lit);
     const int GL = GP * aa;                     // lanes per RNG group
     for (int g = 0; g * GL < 64; ++g) {
       const unsigned long long gm = (litmask >> (g * GL)) & (GL == 64 ? ~0ull : ((1ull << GL) - 1ull));
@@ -166,7 +207,7 @@ __global__ __launch_bounds__(256) void rt_draw_wave(const FrameParams P) {
         while (pm != 0ull) {
           const int j = base + __builtin_ctzll(pm);
           pm &= pm - 1ull;
-          const int cnt = wave_unshadowed(P, T, ns, rl3(start, j), rl3(dir, j), rl(radius_sq, j), jit);
+          const int cnt = wave_unshadowed(P, T, R, lane, ns, rl3(start, j), rl3(dir, j), rl(radius_sq, j), jit);
           if (lane == j) unshadowed = cnt;
         }
       }
@@ -219,7 +260,7 @@ void launch_wave(const FrameParams& P, hipStream_t stream) {
   const dim3 block(256);
   const dim3 grid((P.W + 63) / 64, (P.owned_rows + 3) / 4);
   const size_t lds_bytes = (size_t)P.n * kLdsRecords * sizeof(float4) + (size_t)((P.n + 3) & ~3) * sizeof(int) +
-                           4 * kRngPixels * kRngStride * sizeof(uint32_t);
+                           4 * (size_t)kWaveLdsBytes;
   hipLaunchKernelGGL(rt_draw_wave, grid, block, lds_bytes, stream, P);
 }
 

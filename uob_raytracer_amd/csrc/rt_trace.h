@@ -95,7 +95,7 @@ __device__ void closest_hit(const LdsScene& S, const FrameParams& P, Ray& ray, W
   for (int i = 0; i < S.n; ++i) {
     const f3 v0 = xyz(S.v0[i]), e1 = xyz(S.e1[i]), e2 = xyz(S.e2[i]), c = xyz(S.c[i]);
     const f3 b = ray.start - v0;
-    const float detA_recip = rcp_strict(detc(nd, c));
+    const float detA_recip = rcp_exact(detc(nd, c));
     const float t = detc(b, c) * detA_recip;
     const float u = detc(nd, cof(b, e2)) * detA_recip;
     const float v = detc(nd, cof(e1, b)) * detA_recip;
@@ -121,7 +121,7 @@ __device__ void closest_hit_primary(const LdsScene& S, const FrameParams& P, Ray
   int best = -1;
   for (int i = 0; i < S.n; ++i) {
     const float4 c4 = S.c[i];
-    const float detA_recip = rcp_strict(detc(nd, xyz(c4)));
+    const float detA_recip = rcp_exact(detc(nd, xyz(c4)));
     const float t = c4.w * detA_recip;
     const float u = detc(nd, xyz(S.pc[i])) * detA_recip;
     const float v = detc(nd, xyz(S.qc[i])) * detA_recip;
@@ -171,7 +171,7 @@ __device__ bool in_shadow(const LdsScene& S, const FrameParams& P, f3 start, f3 
     if (S.col[i].w == -1.0f) continue;
     const f3 v0 = xyz(S.v0[i]), c = xyz(S.c[i]);
     const f3 b = start - v0;
-    const float detA_recip = rcp_strict(detc(nd, c));
+    const float detA_recip = rcp_exact(detc(nd, c));
     const float t = detc(b, c) * detA_recip;
     const f3 dv = t * dir;
     const float dist = dv.x * dv.x + dv.y * dv.y + dv.z * dv.z;
