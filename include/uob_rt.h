@@ -60,6 +60,8 @@ typedef struct rt_config {
 
 #define RT_FLAG_FAST_MATH 1u    /* allow FMA contraction + v_rcp/v_rsq: NOT bit-exact */
 #define RT_FLAG_GENERIC_KERNEL 2u   /* always use the one-thread-per-pixel kernel (A/B and parity tests)  */
+#define RT_FLAG_NO_CULL 4u          /* wave kernel: test every triangle for every surface point (no interval
+                                       culling); output is bit-identical either way                        */
 
 typedef struct rt_ctx rt_ctx;
 

@@ -1,0 +1,85 @@
+"""-m gpu: the interval cull of the wave kernel must never change a pixel.
+
+Three code paths render the same frame — wave kernel with the cull (default), wave kernel testing every
+triangle (RT_FLAG_NO_CULL) and the one-thread-per-pixel kernel (RT_FLAG_GENERIC_KERNEL) — and must agree
+bit for bit (ARGB and float tap) over a sweep of lights (incl. close to surfaces and outside the box),
+cameras, jitter spreads and materials.  The generic kernel itself is pinned to the CPU oracle in
+test_gpu_parity.py.
+"""
+import numpy as np
+import pytest
+
+from conftest import focal_for
+from uob_raytracer_amd import abi, runtime as rt
+
+pytestmark = pytest.mark.gpu
+
+LIGHTS = [
+    [0.0, -0.5, -0.7], [-0.3, -0.5, -0.7], [0.5, -0.5, -0.7], [0.0, -0.95, 0.0], [0.9, 0.0, 0.0],
+    [0.0, 0.9, -0.5], [-0.6, 0.4, 0.3], [0.3, 0.55, -0.45], [0.0, 0.0, -2.0], [0.95, 0.95, 0.95],
+]
+CAMS = [(0.0, 0.0, [0.0, 0.0, -3.2]), (0.4, 0.1, [0.3, 0.0, -2.8]), (-0.7, -0.3, [-0.5, 0.2, -2.5])]
+SPREADS = [0.05, 0.0, 0.4]
+
+
+def _render(cfg_kwargs, flags, scene, rot, cam, light):
+    cfg = abi.make_config(flags=flags, **cfg_kwargs)
+    tr = rt.RayTracer(cfg, scene)
+    argb, rgb = tr.render(rot, cam, light, focal_for(cfg), want_rgb=True)
+    tr.close()
+    return argb, rgb
+
+
+@pytest.mark.parametrize("spread", SPREADS)
+@pytest.mark.parametrize("li", range(len(LIGHTS)))
+def test_cull_equals_brute_force(li, spread, scene):
+    kw = dict(width=256, height=256, aa_x=2, aa_y=2, shadow_samples=64, light_spread=spread)
+    yaw, pitch, cam = CAMS[li % len(CAMS)]
+    rot = rt.rotation_matrix(yaw, pitch)
+    a0, f0 = _render(kw, 0, scene, rot, cam, LIGHTS[li])
+    a1, f1 = _render(kw, abi.RT_FLAG_NO_CULL, scene, rot, cam, LIGHTS[li])
+    bad = np.argwhere(a0 != a1)
+    assert bad.size == 0, "cull changed %d pixels, first at %s" % (len(bad), bad[0])
+    assert np.array_equal(f0.view(np.uint32), f1.view(np.uint32))
+
+
+@pytest.mark.parametrize("li", [0, 3, 6, 9])
+def test_wave_equals_generic_kernel(li, scene):
+    kw = dict(width=192, height=128, aa_x=4, aa_y=2, shadow_samples=64)
+    yaw, pitch, cam = CAMS[li % len(CAMS)]
+    rot = rt.rotation_matrix(yaw, pitch)
+    a0, f0 = _render(kw, 0, scene, rot, cam, LIGHTS[li])
+    a2, f2 = _render(kw, abi.RT_FLAG_GENERIC_KERNEL, scene, rot, cam, LIGHTS[li])
+    assert np.array_equal(a0, a2)
+    assert np.array_equal(f0.view(np.uint32), f2.view(np.uint32))
+
+
+def test_materials_mirror_wall_and_glass_panel(scene):
+    """configs[2]-style scene: one wall turned into a mirror, a glass triangle pair (casts no shadow)."""
+    s = scene.with_color([8, 9], (1.0, 1.0, 1.0, 0.0)).with_color([16, 17], (0.0, 0.0, 0.0, -1.0))
+    kw = dict(width=256, height=192, aa_x=2, aa_y=2, shadow_samples=64, max_bounces=5)
+    rot = rt.rotation_matrix(0.2, -0.1)
+    cam, light = [0.1, 0.0, -3.0], [0.2, -0.4, -0.6]
+    a0, f0 = _render(kw, 0, s, rot, cam, light)
+    a1, f1 = _render(kw, abi.RT_FLAG_NO_CULL, s, rot, cam, light)
+    a2, f2 = _render(kw, abi.RT_FLAG_GENERIC_KERNEL, s, rot, cam, light)
+    assert np.array_equal(a0, a1) and np.array_equal(a0, a2)
+    assert np.array_equal(f0.view(np.uint32), f1.view(np.uint32)) and np.array_equal(f0.view(np.uint32), f2.view(np.uint32))
+
+
+def test_headline_frame_cull_vs_brute_force_full_size(scene):
+    """BASELINE.json's headline frame (4096^2, 4x2 AA, 64 shadow rays): cull on == cull off, every pixel."""
+    kw = dict(width=4096, height=4096, aa_x=4, aa_y=2, shadow_samples=64)
+    rot = rt.rotation_matrix(0.0, 0.0)
+    cam, light = [0.0, 0.0, -3.2], [0.0, -0.5, -0.7]
+    cfg = abi.make_config(**kw)
+    tr = rt.RayTracer(cfg, scene)
+    a0 = tr.render(rot, cam, light, focal_for(cfg))
+    tr.close()
+    cfg = abi.make_config(flags=abi.RT_FLAG_NO_CULL, **kw)
+    tr = rt.RayTracer(cfg, scene)
+    a1 = tr.render(rot, cam, light, focal_for(cfg))
+    tr.close()
+    assert np.array_equal(a0, a1)
+    # properties the reference frame has at every size: border rows/columns miss the box
+    assert (a0[0] == 0xFF000000).all() and (a0[:, 0] == 0xFF000000).all()

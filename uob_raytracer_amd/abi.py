@@ -6,6 +6,7 @@ RT_MAX_SPHERES = 4
 RT_OK, RT_E_INVALID, RT_E_DEVICE, RT_E_NOMEM, RT_E_IO, RT_E_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 RT_FLAG_FAST_MATH = 1
 RT_FLAG_GENERIC_KERNEL = 2
+RT_FLAG_NO_CULL = 4
 
 
 class RtSphere(C.Structure):

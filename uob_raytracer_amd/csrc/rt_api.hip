@@ -7,6 +7,7 @@
 // There is no CPU fallback: without a HIP device every device entry point fails with RT_E_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -30,7 +31,7 @@ void set_error(const char* fmt, ...) {
 }
 
 void launch_generic(const FrameParams& P, bool count, hipStream_t stream);
-void launch_wave(const FrameParams& P, hipStream_t stream);
+void launch_wave(const FrameParams& P, bool cull, hipStream_t stream);
 bool wave_kernel_supports(const FrameParams& P);
 
 }  // namespace uobrt
@@ -73,6 +74,13 @@ static int validate_config(const rt_config* c) {
   if (c->band_count < 1 || c->band_index < 0 || c->band_index >= c->band_count || c->band_rows < 1) {
     set_error("band partition invalid (rows=%d index=%d count=%d)", c->band_rows, c->band_index, c->band_count); return RT_E_INVALID;
   }
+  if (!(c->light_spread >= 0.0f) || !(c->light_spread <= 1048576.0f)) { set_error("light_spread must be in [0, 2^20]"); return RT_E_INVALID; }
+  for (int i = 0; i < c->num_spheres; ++i) {
+    const rt_sphere& s = c->spheres[i];
+    for (int k = 0; k < 3; ++k)
+      if (!(fabsf(s.center[k]) <= 1048576.0f)) { set_error("sphere %d: |centre| must be finite and <= 2^20", i); return RT_E_INVALID; }
+    if (!(fabsf(s.radius_sq) <= 1099511627776.0f)) { set_error("sphere %d: radius_sq must be finite and <= 2^40", i); return RT_E_INVALID; }
+  }
   if ((double)c->width * c->height > 16777216.0) {
     // global_id = y*W+x is formed in FP32 by the reference (kernels.cl:380): exact only up to 2^24
     set_error("width*height must not exceed 2^24 (the reference's FP32 pixel id)"); return RT_E_INVALID;
@@ -114,6 +122,13 @@ int rt_init(const rt_config* cfg, const float* vertices4, const float* normals4,
   int rc = validate_config(cfg);
   if (rc != RT_OK) return rc;
   if (n < 0 || (n > 0 && (!vertices4 || !normals4 || !colors4))) { set_error("scene arrays missing"); return RT_E_INVALID; }
+  // Coordinate bound: keeps every determinant of the intersection tests below 2^126, the range in which
+  // the v_rcp_f32 + Newton reciprocal equals IEEE division bit for bit (rt_math.h rcp_exact).
+  for (size_t k = 0; k < (size_t)n * 12; ++k) {
+    if ((k & 3) != 3 && !(fabsf(vertices4[k]) <= 1048576.0f)) {
+      set_error("vertex %zu: coordinates must be finite and |x| <= 2^20", k / 4); return RT_E_INVALID;
+    }
+  }
   if (cfg->flags & RT_FLAG_FAST_MATH) { set_error("RT_FLAG_FAST_MATH is not built into this library"); return RT_E_UNSUPPORTED; }
   if ((size_t)n * 8 * sizeof(float4) > 64 * 1024) {
     set_error("triangle list of %d does not fit one LDS stage (max %d); tiled staging is not available yet", n, (int)(64 * 1024 / 128));
@@ -179,13 +194,17 @@ static void fill_params(const rt_ctx* c, const float rot[12], const float cam[3]
 static int launch_frame(rt_ctx* c, const float rot[12], const float cam[3], const float light[3], float focal,
                         uint32_t* d_argb, float4* d_rgb, hipStream_t stream) {
   if (!c || !rot || !cam || !light) { set_error("NULL argument"); return RT_E_INVALID; }
+  for (int k = 0; k < 3; ++k)
+    if (!(fabsf(cam[k]) <= 1048576.0f) || !(fabsf(light[k]) <= 1048576.0f)) {
+      set_error("camera / light coordinates must be finite and <= 2^20"); return RT_E_INVALID;
+    }
   if (c->owned_rows == 0) return RT_OK;
   FrameParams P;
   fill_params(c, rot, cam, light, focal, &P);
   P.out_argb = d_argb; P.out_rgb = d_rgb; P.counters = nullptr;
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipEventRecord(c->ev0, stream));
-  if (!(c->cfg.flags & RT_FLAG_GENERIC_KERNEL) && wave_kernel_supports(P)) launch_wave(P, stream);
+  if (!(c->cfg.flags & RT_FLAG_GENERIC_KERNEL) && wave_kernel_supports(P)) launch_wave(P, !(c->cfg.flags & RT_FLAG_NO_CULL), stream);
   else launch_generic(P, false, stream);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(c->ev1, stream));
