@@ -49,11 +49,12 @@ def main():
     ap.add_argument("--band-rows", type=int, default=32)
     ap.add_argument("--cpu-sample-pixels", type=int, default=0, help="0 = auto (about 10-30 s of CPU work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-brute-force", action="store_true", help="skip the cull-off comparison leg (N=1 only)")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    from uob_raytracer_amd import abi, runtime as rt
+    from uob_raytracer_amd import abi, bands, runtime as rt
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -81,30 +82,33 @@ def main():
 
     stripe = torch.empty((rows, W), dtype=torch.int32, device=dev)
     gathered = None
-    if world > 1:
-        if H % (band_rows * world) != 0:
-            sys.exit("height must be a multiple of band_rows*gpus for the equal-size gather")
-        if rank == 0:
-            gathered = [torch.empty((rows, W), dtype=torch.int32, device=dev) for _ in range(world)]
-    frame = torch.empty((H, W), dtype=torch.int32, device=dev) if rank == 0 else None
+    bands.check_partition(H, world, band_rows)
+    if world > 1 and rank == 0:
+        gathered = [torch.empty((rows, W), dtype=torch.int32, device=dev) for _ in range(world)]
+    frame = torch.empty((H, W), dtype=torch.int32, device=dev) if (rank == 0 and world > 1) else None
 
-    def step():
-        stream = torch.cuda.current_stream().cuda_stream
-        tracer.render_device(rot, cam, light, focal, stripe.data_ptr(), None, stream)
-        if world > 1:
-            dist.gather(stripe, gathered, dst=0)
-            if rank == 0:   # [rank, band, row, x] -> [band, rank, row, x] = image order
-                g = torch.stack(gathered).view(world, -1, band_rows, W)
-                frame.view(-1, world, band_rows, W).copy_(g.permute(1, 0, 2, 3))
-        # N == 1: the kernel's output buffer IS the frame
+    def step(ev=None):
+        # the HIP kernel, enqueued on torch's current stream through the C ABI
+        if ev:
+            ev[0].record()
+        tracer.render_device(rot, cam, light, focal, stripe.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+        if ev:
+            ev[1].record()
+        # N > 1: one RCCL gather of the finished bands + de-interleave on rank 0; N == 1: the stripe IS the frame
+        bands.gather_frame(stripe, world, rank, band_rows, gathered, frame)
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # exact algorithmic work of this rank's bands (un-timed instrumented pass)
+    # exact algorithmic work of this rank's bands (un-timed instrumented passes): `work` follows the
+    # reference's loops literally (rt_count_work); `executed` is what the wave kernel really runs
     work = tracer.count_work(rot, cam, light, focal)
+    try:
+        executed = tracer.count_executed(rot, cam, light, focal)
+    except rt.RtError:
+        executed = {}
 
     for _ in range(args.warmup):
         step()
@@ -112,20 +116,14 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for k in range(args.steps):
-        ev[k][0].record()
-        tracer.render_device(rot, cam, light, focal, stripe.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
-        ev[k][1].record()
-        if world > 1:
-            dist.gather(stripe, gathered, dst=0)
-            if rank == 0:
-                g = torch.stack(gathered).view(world, -1, band_rows, W)
-                frame.view(-1, world, band_rows, W).copy_(g.permute(1, 0, 2, 3))
+        step(ev[k])
     sync()
     elapsed = time.perf_counter() - t0
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
-    keys = list(work)
-    stats = torch.tensor([elapsed, kernel_ms] + [float(work[k]) for k in keys], dtype=torch.float64, device=dev)
+    keys, xkeys = list(work), list(executed)
+    stats = torch.tensor([elapsed, kernel_ms] + [float(work[k]) for k in keys] + [float(executed[k]) for k in xkeys],
+                         dtype=torch.float64, device=dev)
     if world > 1:
         mx = stats[:2].clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -134,9 +132,10 @@ def main():
         stats = torch.cat([mx, sm])
     stats = stats.cpu().numpy()
     elapsed, kernel_ms = float(stats[0]), float(stats[1])
-    total_work = {k: int(round(v)) for k, v in zip(keys, stats[2:])}
+    total_work = {k: int(round(v)) for k, v in zip(keys, stats[2:2 + len(keys)])}
+    total_exec = {k: int(round(v)) for k, v in zip(xkeys, stats[2 + len(keys):])}
 
-    # frame integrity: rank 0 hashes the final frame (N=1: the stripe is the frame)
+    # frame integrity: rank 0 sums the final frame (N=1: the stripe is the frame)
     if rank == 0:
         final = stripe if world == 1 else frame
         frame_sum = int(final.to(torch.int64).bitwise_and(0xFFFFFFFF).sum().item())
@@ -159,6 +158,27 @@ def main():
     hbm_bytes_per_launch = W * (H // world) * 4 + wg * len(scene) * 80
     achieved_gbps = hbm_bytes_per_launch / (kernel_ms * 1e-3) / 1e9
 
+    roofline = {"bound": "valu", "achieved": achieved_tflops, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved_tflops / PEAK_FP32_VALU_TFLOPS, "traffic": None,
+                "note": "FP32 vector-ALU roof (SURVEY.md 8d; this path is neither HBM- nor MFMA-bound). achieved = "
+                        "ALGORITHMIC flop: (triangle tests*46 + sphere tests*30) of the reference's brute-force loops "
+                        "per launch / kernel time. The kernel resolves most (surface point, triangle) pairs by an exact "
+                        "interval bound instead of 64 per-sample tests, so the algorithmic rate can exceed the "
+                        "hardware peak; `executed` is the arithmetic really issued."}
+    if total_exec:
+        ns = len(scene)   # shadow-casting triangles (no glass in the shipped scene)
+        ex_flop = 64 * (total_exec["stage1_wave_iterations"] * 19 + total_exec["stage2_wave_iterations"] * 13) + \
+            total_exec["surface_points"] * ns * 64 + \
+            (total_work["closest_tri_tests"] * 27 + total_work["closest_sphere_tests"] * 30)
+        ex_tflops = ex_flop / world / (kernel_ms * 1e-3) / 1e12
+        roofline["executed"] = {
+            "sample_triangle_tests": 64 * total_exec["stage1_wave_iterations"],
+            "fraction_of_reference_tests": 64 * total_exec["stage1_wave_iterations"] / max(total_work["shadow_tri_tests"], 1),
+            "culled_pairs": total_exec["culled_pairs"], "surface_points": total_exec["surface_points"],
+            "tflops": ex_tflops, "frac": ex_tflops / PEAK_FP32_VALU_TFLOPS,
+            "note": "flop issued by the kernel: 19 per first-stage sample test, 13 per second-stage, 64 per "
+                    "(surface point, triangle) set-up+bound, 27/30 per primary/bounce closest-hit test"}
+
     out = {
         "metric": "Mrays/sec (nominal = W*H*AA*(1+S)/t), Cornell Box 4096^2, 8xAA, 64 shadow rays",
         "value": nominal_rays / (ms_per_step * 1e-3) / 1e6,
@@ -179,32 +199,55 @@ def main():
         "work_per_frame": total_work,
         "frame_checksum": frame_sum,
         "parity": "bit-exact vs CPU oracle (strict FP32, reference operation order); tolerance allowed 1e-4",
-        "roofline": {"bound": "valu", "achieved": achieved_tflops, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved_tflops / PEAK_FP32_VALU_TFLOPS, "traffic": None,
-                     "note": "FP32 vector ALU roof (SURVEY.md 8d): (tri_tests*46 + sphere_tests*30) flop per launch / kernel time"},
+        "roofline": roofline,
         "roofline_hbm": {"bound": "hbm", "achieved": achieved_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                          "frac": achieved_gbps / PEAK_HBM_GBPS, "traffic": None,
                          "note": "algorithmic bytes = 4 B/pixel ARGB + 80 B/triangle per workgroup; <<1% by construction"},
     }
 
+    if world == 1 and not args.no_brute_force and total_exec:
+        # the same frame with the interval cull switched off (every triangle tested for every surface point)
+        bcfg = abi.make_config(flags=abi.RT_FLAG_NO_CULL, device=local_rank, **wl)
+        bt = rt.RayTracer(bcfg, scene)
+        bstripe = torch.empty((H, W), dtype=torch.int32, device=dev)
+        bt.render_device(rot, cam, light, focal, bstripe.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            bt.render_device(rot, cam, light, focal, bstripe.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+        e1.record()
+        torch.cuda.synchronize()
+        bms = e0.elapsed_time(e1) / 3
+        out["brute_force"] = {"kernel_ms_per_launch": bms, "value": nominal_rays / (bms * 1e-3) / 1e6,
+                              "roofline_frac": flops / (bms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS,
+                              "identical_frame": bool(torch.equal(bstripe, stripe)),
+                              "note": "RT_FLAG_NO_CULL: same kernel, all triangles tested for every surface point"}
+        bt.close()
+
     if not args.no_cpu_baseline:
         from oracle import pyref   # checker, used here only as the timed CPU baseline
         # the GPU box gives one-GPU jobs a 16-core share: never use more host threads than that
         cores = min(len(os.sched_getaffinity(0)), 16)
-        npx = args.cpu_sample_pixels or 60000
         rng = np.random.default_rng(12345)
-        pix = rng.choice(W * H, size=npx, replace=False).astype(np.int32)
         full = abi.make_config(**wl)
         v, n, c = scene.packed()
         orc = pyref.Oracle()
-        orc.render(full, v, n, c, rot, cam, light, focal, pix=pix[:256], nthreads=cores)   # warm
+        npx = args.cpu_sample_pixels
+        if not npx:     # calibrate on 4000 pixels, then size the sample for about 12 s of CPU work
+            cal = rng.choice(W * H, size=4000, replace=False).astype(np.int32)
+            t0 = time.perf_counter()
+            orc.render(full, v, n, c, rot, cam, light, focal, pix=cal, nthreads=cores)
+            npx = int(min(W * H, max(4000, 12.0 / max(time.perf_counter() - t0, 1e-4) * 4000)))
+        pix = rng.choice(W * H, size=npx, replace=False).astype(np.int32)
         t0 = time.perf_counter()
         o_argb, _ = orc.render(full, v, n, c, rot, cam, light, focal, pix=pix, nthreads=cores)
         dt = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": npx * aa * (1 + cfg.shadow_samples) / dt / 1e6, "unit": "Mrays/s", "cores": cores,
                                "kind": "port", "seconds": dt,
-                               "sample": "%d random pixels of the same %dx%d frame (%.3g nominal rays), CPU oracle, OpenMP" % (
-                                   npx, W, H, npx * aa * (1 + cfg.shadow_samples))}
+                               "sample": "%d random pixels of the same %dx%d frame (%.3g nominal rays), CPU oracle "
+                                         "(oracle/rt_oracle.c, OpenMP, %d threads)" % (
+                                             npx, W, H, npx * aa * (1 + cfg.shadow_samples), cores)}
         # the sampled pixels double as an in-bench parity check of the frame just timed
         got = (stripe if world == 1 else frame).view(-1)[torch.from_numpy(pix.astype(np.int64)).to(dev)].cpu().numpy().view(np.uint32)
         out["cpu_baseline"]["gpu_frame_matches_oracle_on_sample"] = bool(np.array_equal(got, o_argb))

@@ -107,6 +107,14 @@ int rt_render_device(rt_ctx* ctx, const float rot[12], const float cam[3], const
 int rt_count_work(rt_ctx* ctx, const float rot[12], const float cam[3], const float light[3],
                   float focal, rt_work* out);
 
+/* Work the 64-sample wave kernel actually EXECUTES for the frame (un-timed instrumented pass; fails with
+ * RT_E_UNSUPPORTED for configurations that run on the generic kernel).  out[0] = surface points lit,
+ * out[1] = first-stage (t) wave iterations = 64 sample tests each, out[2] = second-stage (u,v) wave
+ * iterations, out[3] = wave-wide sphere evaluations, out[4] = (surface point, triangle) pairs removed by
+ * the interval cull, out[5..7] = 0.                                                                    */
+int rt_count_executed(rt_ctx* ctx, const float rot[12], const float cam[3], const float light[3],
+                      float focal, uint64_t out[8]);
+
 /* Device time of the most recent rt_render / rt_render_device kernel(s) on this context in ms,
  * measured with hipEvents on the launch stream (synchronises that stream).                          */
 int rt_last_kernel_ms(rt_ctx* ctx, float* out_ms);

@@ -129,10 +129,16 @@ def pack_scene(aos):
     return verts.reshape(n * 3, 4), normals, colors
 
 
+_libm = C.CDLL("libm.so.6")
+_libm.cosf.restype = _libm.sinf.restype = C.c_float
+_libm.cosf.argtypes = _libm.sinf.argtypes = [C.c_float]
+
+
 def rot_matrix(yaw, pitch):
-    """skeleton.cpp:149-151, evaluated in float32 like the reference's float cos/sin."""
+    """skeleton.cpp:149-151: float cos/sin (glm::cos(float) -> cosf) and float products."""
     f = np.float32
-    cy, sy, cp, sp = f(np.cos(f(yaw))), f(np.sin(f(yaw))), f(np.cos(f(pitch))), f(np.sin(f(pitch)))
+    cy, sy = f(_libm.cosf(yaw)), f(_libm.sinf(yaw))
+    cp, sp = f(_libm.cosf(pitch)), f(_libm.sinf(pitch))
     return np.array([cy, sp * sy, sy * cp, 0.0, 0.0, cp, -sp, 0.0, -sy, cy * sp, cp * cy, 0.0], np.float32)
 
 

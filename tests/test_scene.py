@@ -1,0 +1,67 @@
+"""CPU: the product's scene builders (host code of libuob_rt.so, no GPU needed) against vectors produced
+by the reference's own LoadTestModel / load_obj (tests/golden/make_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pyref
+from uob_raytracer_amd import runtime as rt
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_cornell_box_bitwise(scene):
+    want = np.load(os.path.join(G, "scene_cornell_aos.npy"))
+    assert len(scene) == 26
+    assert np.array_equal(scene.aos.view(np.uint32), want.view(np.uint32))
+
+
+def test_packed_buffer_hashes(scene):
+    """SURVEY.md 8(c) known answers of the three upload buffers (skeleton.cpp:474-484)."""
+    v, n, c = scene.packed()
+    assert "%016x" % pyref.fnv1a64_bytes(v.tobytes()) == "ca526ec88377e6cf"
+    assert "%016x" % pyref.fnv1a64_bytes(n.tobytes()) == "fabe0e69451ae797"
+    assert "%016x" % pyref.fnv1a64_bytes(c.tobytes()) == "14c3d6f39db733b3"
+    assert (v[:, 3] == 0).all() and (n[:, 3] == 0).all()
+    assert set(np.unique(c[:, 3])) == {1.0}     # the shipped scene is all diffuse
+
+
+def test_obj_loader_bitwise():
+    got = rt.Scene.load_obj(os.path.join(G, "mesh_small.obj")).aos
+    want = np.load(os.path.join(G, "mesh_small_aos.npy"))
+    assert got.shape == want.shape == (60, 5, 4)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert (got[:, 4, :] == np.array([0.0, 0.2, 0.4, 0.5], np.float32)).all()   # Loader.cpp:20 blue
+    assert (got[:, :3, 3] == 0.0).all()     # (-1)*1 + 1: the loader leaves w = 0 (Loader.cpp:48-52)
+
+
+def test_obj_loader_errors(tmp_path):
+    with pytest.raises(rt.RtError) as e:
+        rt.Scene.load_obj(str(tmp_path / "missing.obj"))
+    assert e.value.code == -4
+    bad = tmp_path / "bad.obj"
+    bad.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 9\n")          # index out of range
+    with pytest.raises(rt.RtError):
+        rt.Scene.load_obj(str(bad))
+    slash = tmp_path / "slash.obj"
+    slash.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1/1 2/2 3/3\n")   # syntax the reference cannot parse either
+    with pytest.raises(rt.RtError):
+        rt.Scene.load_obj(str(slash))
+    empty = tmp_path / "empty.obj"
+    empty.write_text("# nothing\n")
+    assert len(rt.Scene.load_obj(str(empty))) == 0
+
+
+def test_scene_concatenation_like_reference_main(scene):
+    """skeleton.cpp:102-103: triangles.insert(end, bunny...)"""
+    mesh = rt.Scene.load_obj(os.path.join(G, "mesh_small.obj"))
+    both = scene + mesh
+    assert len(both) == 86
+    v, n, c = both.packed()
+    assert v.shape == (258, 4) and c.shape == (86, 4)
+
+
+def test_rotation_matrix_matches_reference_formula():
+    for yaw, pitch in [(0.0, 0.0), (0.3, -0.2), (-1.1, 0.7)]:
+        assert np.array_equal(rt.rotation_matrix(yaw, pitch), pyref.rot_matrix(yaw, pitch))

@@ -1,0 +1,45 @@
+"""Row-band partition of one frame over the ranks of a torch.distributed job, and the gather that
+rebuilds the frame on rank 0.
+
+The reference has a single device; pixels are independent and the scene is 2 KB, so the
+frame shards with no exchange during rendering.  Rank r owns the bands r, r+N, r+2N, ... of `band_rows`
+rows each (rt_config.band_* in include/uob_rt.h) — interleaved rather than contiguous stripes because
+the top/bottom rows of the Cornell-Box view are empty and the sphere rows are costlier.
+The only collective is one gather of the finished ARGB bands to rank 0 (RCCL on GPUs, gloo in the CPU
+tests).  torch is used for device memory and torch.distributed only.
+"""
+
+
+def band_rows_of(rank, world, height, band_rows):
+    """Global row indices owned by `rank`, in the packed order of its output buffer."""
+    return [y for y in range(height) if (y // band_rows) % world == rank]
+
+
+def check_partition(height, world, band_rows):
+    if world > 1 and height % (band_rows * world) != 0:
+        raise ValueError("height %d must be a multiple of band_rows*world = %d for the equal-size gather"
+                         % (height, band_rows * world))
+
+
+def gather_frame(stripe, world, rank, band_rows, gather_list=None, frame=None, dst=0):
+    """Gather every rank's packed bands to `dst` and de-interleave them into image order.
+
+    stripe: [rows_owned, W] integer tensor (ARGB words) on this rank.  Returns the [H, W] frame on `dst`
+    (written into `frame` when given) and None elsewhere.  With world == 1 the stripe is the frame.
+    """
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return stripe
+    rows, width = stripe.shape
+    if rank == dst and gather_list is None:
+        gather_list = [torch.empty_like(stripe) for _ in range(world)]
+    dist.gather(stripe, gather_list if rank == dst else None, dst=dst)
+    if rank != dst:
+        return None
+    if frame is None:
+        frame = torch.empty((rows * world, width), dtype=stripe.dtype, device=stripe.device)
+    # [rank, band, row, x] -> [band, rank, row, x] == image order
+    g = torch.stack(gather_list).view(world, -1, band_rows, width)
+    frame.view(-1, world, band_rows, width).copy_(g.permute(1, 0, 2, 3))
+    return frame

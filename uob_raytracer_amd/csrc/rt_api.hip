@@ -31,7 +31,7 @@ void set_error(const char* fmt, ...) {
 }
 
 void launch_generic(const FrameParams& P, bool count, hipStream_t stream);
-void launch_wave(const FrameParams& P, bool cull, hipStream_t stream);
+void launch_wave(const FrameParams& P, bool cull, bool count, hipStream_t stream);
 bool wave_kernel_supports(const FrameParams& P);
 
 }  // namespace uobrt
@@ -204,7 +204,7 @@ static int launch_frame(rt_ctx* c, const float rot[12], const float cam[3], cons
   P.out_argb = d_argb; P.out_rgb = d_rgb; P.counters = nullptr;
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipEventRecord(c->ev0, stream));
-  if (!(c->cfg.flags & RT_FLAG_GENERIC_KERNEL) && wave_kernel_supports(P)) launch_wave(P, !(c->cfg.flags & RT_FLAG_NO_CULL), stream);
+  if (!(c->cfg.flags & RT_FLAG_GENERIC_KERNEL) && wave_kernel_supports(P)) launch_wave(P, !(c->cfg.flags & RT_FLAG_NO_CULL), false, stream);
   else launch_generic(P, false, stream);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(c->ev1, stream));
@@ -246,6 +246,26 @@ int rt_count_work(rt_ctx* c, const float rot[12], const float cam[3], const floa
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(rt_work), c->stream));
   launch_generic(P, true, c->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(out, c->d_counters, sizeof(rt_work), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RT_OK;
+}
+
+int rt_count_executed(rt_ctx* c, const float rot[12], const float cam[3], const float light[3], float focal, uint64_t out[8]) {
+  if (!c || !out || !rot || !cam || !light) { set_error("NULL argument"); return RT_E_INVALID; }
+  memset(out, 0, 8 * sizeof(uint64_t));
+  if (c->owned_rows == 0) return RT_OK;
+  FrameParams P;
+  fill_params(c, rot, cam, light, focal, &P);
+  if ((c->cfg.flags & RT_FLAG_GENERIC_KERNEL) || !wave_kernel_supports(P)) {
+    set_error("rt_count_executed: this configuration runs on the generic kernel, whose executed work is rt_count_work");
+    return RT_E_UNSUPPORTED;
+  }
+  P.counters = c->d_counters;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(rt_work), c->stream));
+  launch_wave(P, !(c->cfg.flags & RT_FLAG_NO_CULL), true, c->stream);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(out, c->d_counters, sizeof(rt_work), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));

@@ -79,9 +79,9 @@ __device__ __forceinline__ WaveLds wave_lds(char* base) {
 // towards the light that are NOT blocked: kernels.cl:243-311 evaluated for 64 samples at once.
 //   dminlen, dk : lower bound of |d| over the jitter box and sqrt(radius_sq)*(1+slack), for the cull
 //   sph_maybe   : false when no sample's ray can reach a shadow-casting sphere
-template <bool CULL>
+template <bool CULL, bool COUNT>
 __device__ __forceinline__ int wave_unshadowed(const FrameParams& P, const TriLane& T, const WaveLds& L, int lane, int ns,
-                                               int j, float dminlen, float dk, bool sph_maybe, f3 jit) {
+                                               int j, float dminlen, float dk, bool sph_maybe, f3 jit, Work& wk) {
   const float4 h0 = L.h0[j], h1 = L.h1[j];                 // LDS broadcasts
   const f3 start = mk(h0.x, h0.y, h0.z), dir = mk(h1.x, h1.y, h1.z);
   const float radius_sq = h0.w;
@@ -120,6 +120,7 @@ __device__ __forceinline__ int wave_unshadowed(const FrameParams& P, const TriLa
       keep = keep && !(robust && (cS || cR || cU || cV || cW));
     }
     cand = ballot(keep);
+    if (COUNT) { wk.v[0] += 1; wk.v[4] += (unsigned)(ns - __popcll(cand)); }
   }
   __builtin_amdgcn_wave_barrier();
   // ---- 64 samples against each candidate triangle ---------------------------------------------------
@@ -141,7 +142,9 @@ __device__ __forceinline__ int wave_unshadowed(const FrameParams& P, const TriLa
       // first stage, :266.  The negated compares are also true for NaN, so a lane whose reciprocal needs
       // the division fallback reaches the second stage, where it is recomputed exactly.
       unsigned long long pass = ballot(!(t < 0.0f)) & ballot(!(dist >= radius_sq));
+      if (COUNT) wk.v[1] += 1;
       if ((pass & ~shadowed) != 0ull) {                                // wave-uniform second stage
+        if (COUNT) wk.v[2] += 1;
         if (ballot(rr != rr) != 0ull) {                                // rare: reciprocal outside v_rcp's range
           rr = 1.0f / detA;
           t = r0.w * rr;
@@ -165,8 +168,9 @@ __device__ __forceinline__ int wave_unshadowed(const FrameParams& P, const TriLa
   __builtin_amdgcn_wave_barrier();
   bool sh = (shadowed >> lane) & 1ull;
   if (sph_maybe && shadowed != ~0ull) {
-    Work wk;
-    if (!sh) sh = shadow_spheres<false>(P, start, d, radius_sq, wk);
+    Work unused;
+    if (COUNT) wk.v[3] += 1;
+    if (!sh) sh = shadow_spheres<false>(P, start, d, radius_sq, unused);
   }
   return __popcll(ballot(!sh));
 }
@@ -192,7 +196,7 @@ __device__ __forceinline__ bool spheres_maybe(const FrameParams& P, f3 start, f3
 }  // namespace
 
 // Grid: x = ceil(W/64) row segments, y = ceil(owned_rows/4); block = 256 threads = 4 waves = 4 rows.
-template <bool CULL>
+template <bool CULL, bool COUNT>
 __global__ __launch_bounds__(256) void rt_draw_wave(const FrameParams P) {
   extern __shared__ float4 lds[];
   const int tid = threadIdx.x;
@@ -231,7 +235,8 @@ __global__ __launch_bounds__(256) void rt_draw_wave(const FrameParams P) {
   }
 
   f3 outc = mk(0.f, 0.f, 0.f);
-  Work wk;
+  Work wk, xw;                               // xw: executed-work counters of this wave (COUNT builds only)
+  if (COUNT) for (int q = 0; q < 8; ++q) xw.v[q] = 0;
   for (int k = 0; k < aa; ++k) {
     // ---- phase 1: 64 primary rays, lane = (pixel, AA sample) -----------------------------------------
     const int pj = k * PT + (lane >> la);       // pixel of this lane within the 64-pixel job
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(256) void rt_draw_wave(const FrameParams P) {
         while (pm != 0ull) {
           const int j = base + __builtin_ctzll(pm);
           pm &= pm - 1ull;
-          const int cnt = wave_unshadowed<CULL>(P, T, L, lane, ns, j, rl(dminlen, j), rl(dk, j), (sphmask >> j) & 1ull, jit);
+          const int cnt = wave_unshadowed<CULL, COUNT>(P, T, L, lane, ns, j, rl(dminlen, j), rl(dk, j), (sphmask >> j) & 1ull, jit, xw);
           if (lane == j) unshadowed = cnt;
         }
       }
@@ -327,6 +332,10 @@ __global__ __launch_bounds__(256) void rt_draw_wave(const FrameParams P) {
     }
   }
 
+  if (COUNT) {                               // wave-uniform counters: lane 0 publishes them
+    if (lane == 0) for (int q = 0; q < 5; ++q) if (xw.v[q]) atomicAdd(&P.counters[q], xw.v[q]);
+    return;
+  }
   // ---- store: 64 consecutive pixels, one coalesced access per wave ------------------------------------
   const int x = x0 + lane;
   if (x < P.W) {
@@ -338,8 +347,10 @@ __global__ __launch_bounds__(256) void rt_draw_wave(const FrameParams P) {
   }
 }
 
-template __global__ void rt_draw_wave<false>(const FrameParams);
-template __global__ void rt_draw_wave<true>(const FrameParams);
+template __global__ void rt_draw_wave<false, false>(const FrameParams);
+template __global__ void rt_draw_wave<true, false>(const FrameParams);
+template __global__ void rt_draw_wave<false, true>(const FrameParams);
+template __global__ void rt_draw_wave<true, true>(const FrameParams);
 
 bool wave_kernel_supports(const FrameParams& P) {
   const int aa = P.aa_x * P.aa_y;
@@ -347,13 +358,18 @@ bool wave_kernel_supports(const FrameParams& P) {
          P.spread >= 0.0f;
 }
 
-void launch_wave(const FrameParams& P, bool cull, hipStream_t stream) {
+void launch_wave(const FrameParams& P, bool cull, bool count, hipStream_t stream) {
   const dim3 block(256);
   const dim3 grid((P.W + 63) / 64, (P.owned_rows + 3) / 4);
   const size_t lds_bytes = (size_t)P.n * kLdsRecords * sizeof(float4) + (size_t)((P.n + 3) & ~3) * sizeof(int) +
                            4 * (size_t)kWaveLdsBytes;
-  if (cull) hipLaunchKernelGGL(rt_draw_wave<true>, grid, block, lds_bytes, stream, P);
-  else hipLaunchKernelGGL(rt_draw_wave<false>, grid, block, lds_bytes, stream, P);
+  if (count) {
+    if (cull) hipLaunchKernelGGL((rt_draw_wave<true, true>), grid, block, lds_bytes, stream, P);
+    else hipLaunchKernelGGL((rt_draw_wave<false, true>), grid, block, lds_bytes, stream, P);
+  } else {
+    if (cull) hipLaunchKernelGGL((rt_draw_wave<true, false>), grid, block, lds_bytes, stream, P);
+    else hipLaunchKernelGGL((rt_draw_wave<false, false>), grid, block, lds_bytes, stream, P);
+  }
 }
 
 }  // namespace uobrt

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libuob_rt.so")
 
 EXPORTS = (
     "rt_abi_version", "rt_last_error", "rt_config_default", "rt_config_owned_rows", "rt_init", "rt_render",
-    "rt_render_device", "rt_count_work", "rt_last_kernel_ms", "rt_destroy", "rt_scene_cornell_box",
+    "rt_render_device", "rt_count_work", "rt_count_executed", "rt_last_kernel_ms", "rt_destroy", "rt_scene_cornell_box",
     "rt_scene_load_obj", "rt_triangle_compute_normal", "rt_scene_pack", "rt_rotation_matrix", "rt_selftest_rcp",
 )
 
@@ -45,6 +45,7 @@ def lib():
         L.rt_render.argtypes = [vp, fp, fp, fp, C.c_float, C.POINTER(C.c_uint32), fp]
         L.rt_render_device.argtypes = [vp, fp, fp, fp, C.c_float, vp, vp, vp]
         L.rt_count_work.argtypes = [vp, fp, fp, fp, C.c_float, C.POINTER(abi.RtWork)]
+        L.rt_count_executed.argtypes = [vp, fp, fp, fp, C.c_float, C.POINTER(C.c_uint64)]
         L.rt_last_kernel_ms.argtypes = [vp, fp]
         L.rt_destroy.argtypes = [vp]
         L.rt_destroy.restype = None
@@ -187,6 +188,15 @@ class RayTracer:
         w = abi.RtWork()
         _check(lib().rt_count_work(self._h, _fp(rot), _fp(cam), _fp(light), C.c_float(focal), C.byref(w)))
         return w.as_dict()
+
+    def count_executed(self, rot, cam, light, focal):
+        """Executed work of the wave kernel (include/uob_rt.h rt_count_executed)."""
+        rot, cam, light = self._args(rot, cam, light)
+        out = (C.c_uint64 * 8)()
+        _check(lib().rt_count_executed(self._h, _fp(rot), _fp(cam), _fp(light), C.c_float(focal), out))
+        keys = ("surface_points", "stage1_wave_iterations", "stage2_wave_iterations", "sphere_wave_evaluations",
+                "culled_pairs")
+        return {k: int(out[i]) for i, k in enumerate(keys)}
 
     def last_kernel_ms(self):
         ms = C.c_float()
