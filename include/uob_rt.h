@@ -111,7 +111,7 @@ int rt_count_work(rt_ctx* ctx, const float rot[12], const float cam[3], const fl
  * RT_E_UNSUPPORTED for configurations that run on the generic kernel).  out[0] = surface points lit,
  * out[1] = first-stage (t) wave iterations = 64 sample tests each, out[2] = second-stage (u,v) wave
  * iterations, out[3] = wave-wide sphere evaluations, out[4] = (surface point, triangle) pairs removed by
- * the interval cull, out[5..7] = 0.                                                                    */
+ * the per-point interval cull, out[5] = 64-ray tasks resolved whole by the task-level bound, out[6..7] = 0.                                                                    */
 int rt_count_executed(rt_ctx* ctx, const float rot[12], const float cam[3], const float light[3],
                       float focal, uint64_t out[8]);
 

@@ -2,29 +2,33 @@
 //
 // The reference spends ~98 % of its ray-primitive tests in direct_light's shadow loop
 // (Source/kernels.cl:313-340 -> in_shadow :243-311): for ONE surface point, S jittered rays towards the
-// area light are tested against every triangle.  On gfx950 a wavefront is 64 lanes, so for S = 64 this
-// kernel maps   lane = shadow sample   and processes surface points one after another per wave:
+// area light are tested against every triangle.  On gfx950 a wavefront is 64 lanes, so for S = 64 the
+// sample-level work maps   lane = shadow sample   and surface points are processed one after another:
+// all 64 lanes test the same triangle against the same surface point, so the two-stage test of in_shadow
+// (t first, u/v only if t passes, :266) is a WAVE-UNIFORM branch, lane predicates are 64-bit wave masks
+// (one v_cmp each, logic on the scalar unit) and the any-hit early-out is "blocked mask == all ones".
 //
-//   * everything that depends only on (surface point, triangle) — b = start - v0, det(b,e1,e2),
-//     cof(b,e2), cof(e1,b): 26 of the ~45 FP32 operations of one test — is computed ONCE per surface
-//     point, lane-parallel over triangles (lane i = triangle i), and handed to the 64 sample lanes
-//     through per-wave LDS records that every lane reads at the same address (an LDS broadcast);
-//   * all 64 lanes test the same triangle against the same surface point, so the two-stage test of
-//     in_shadow (t first, u/v only if t passes, :266) becomes a WAVE-UNIFORM branch: the u/v stage runs
-//     only when some lane's t passes, with no divergence;
-//   * any-hit early-out is a wave ballot: the triangle loop ends as soon as every lane is shadowed;
-//   * (CULL) while the triangle lanes hold the per-surface-point terms they also bound them over the
-//     whole jitter box of the area light (interval arithmetic on the same determinants, with explicit
-//     slack for every FP32 rounding the test performs): a triangle for which NO sample can pass the
-//     reference's own comparisons is dropped before the sample loop.  The surviving set is a wave
-//     ballot; the result is bit-identical to testing all triangles (tests/test_gpu_parity.py).
+// A wave owns 64 consecutive pixels of one image row (its framebuffer store is one coalesced 256-B ARGB /
+// 1-KiB float4 access) and walks them in `aa` tasks of 64 primary rays (64/aa pixels x aa AA rays):
+//   phase 1  primary rays, lane = (pixel, AA sample);  phase 2  mirror/glass bounces (kernels.cl:342-365)
+//   phase 3  shadows of the 64 surface points (below);  phase 4  shading, AA sum in the reference's order.
 //
-// A wave owns 64 consecutive pixels of one image row (so its framebuffer store is one coalesced 256-B
-// ARGB / 1-KiB float4 access).  It walks them in `aa` tasks of 64 primary rays (64/aa pixels x aa AA
-// rays): phase 1 traces the 64 primary rays lane-parallel, phase 2 follows mirror/glass bounces, phase 3
-// runs the wave-wide shadow test for each lit lane, phase 4 shades lane-parallel and sums the AA rays of
-// a pixel in the reference's order.  The per-pixel xorshift streams (seeded by the GLOBAL pixel id,
-// :319) are generated for 4 pixels at a time by 12 lanes into a per-wave LDS scratch.
+// Phase 3 with CULL (the shipped path) is a three-level exact hierarchy.  The determinants of the
+// reference's test are linear in the ray direction, so over the jitter box of the area light
+// (dir + [-h,h]^3) each is  centre value +- h*|cofactors|_1 ; with explicit slack for every FP32 rounding
+// of the per-sample evaluation these intervals decide, for ALL 64 samples at once, whether the
+// reference's comparisons (t>=0, |t d|^2<r^2, u>=0, v>=0, u+v<=1) can come out true / must come out true:
+//   level 1 (lane = triangle, once per task): bounds over all lit surface points of the task -> the few
+//            triangles K that may matter; or "one triangle blocks everything" -> task done;
+//   level 2 (lane = surface point, loop over K): the same bounds per point -> per point: fully lit,
+//            fully blocked, or the triangles whose samples must really be tested;
+//   level 3 (lane = sample): the reference's test, operation for operation, for those (point, triangle)
+//            pairs only, with the per-pixel xorshift streams (seeded by the GLOBAL pixel id, :319)
+//            generated on demand into per-wave LDS.
+// The result is bit-identical to testing every triangle for every sample (tests/test_gpu_cull.py); the
+// brute-force form of phase 3 (CULL = false, RT_FLAG_NO_CULL) is kept for that comparison: there lanes
+// 0..n-1 act as triangle lanes that compute the sample-independent terms once per surface point and hand
+// them to the sample lanes through LDS records read at a uniform address (an LDS broadcast).
 //
 // Arithmetic is the reference's, operation for operation (rt_math.h): results are bit-identical to the
 // generic kernel and to the CPU oracle.
@@ -42,18 +46,29 @@ __device__ __forceinline__ float rl(float v, int lane) {
 }
 __device__ __forceinline__ float shfl(float v, int lane) { return __shfl(v, lane, 64); }
 __device__ __forceinline__ unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ float norm1(f3 a) { return fabsf(a.x) + fabsf(a.y) + fabsf(a.z); }
+__device__ __forceinline__ float wave_max(float v) {
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+  for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
+  return v;
+}
 
 // Per-lane registers of a "triangle lane" (lane i < ns holds shadow-casting triangle i)
 struct TriLane {
   f3 v0, e1, e2, c;
-  float c1;          // |c.x|+|c.y|+|c.z|
+  float c1, e1_1, e2_1;    // 1-norms |c|, |e1|, |e2| (interval bounds)
 };
 
-// Per-wave LDS.  Records r0..r2: the triangle lanes hand their per-surface-point terms to the 64 sample
-// lanes; every sample lane reads the SAME record, which LDS serves as a broadcast into VGPRs.
-// (Broadcasting through SGPRs instead — v_readlane_b32 — costs 4.3 issue cycles per value and makes
-// every VALU instruction that consumes the SGPR half rate: profiles/r01_valu_issue_cost_8waves.txt.)
-// Records h0,h1: the 64 surface points of the current task, written lane-parallel, read as broadcasts.
+// Per-wave LDS.
+//   r0..r2 (brute-force path): sample-independent terms of (surface point, triangle i), written by
+//          triangle lane i, read by all sample lanes at the same address (LDS broadcast into VGPRs;
+//          broadcasting through SGPRs with v_readlane_b32 costs 4.3 issue cycles per value and makes every
+//          consuming VALU instruction half rate: profiles/r01_valu_issue_cost_8waves.txt)
+//   h0,h1: the 64 surface points of the current task, written lane-parallel, read as broadcasts
+//   rng  : xorshift streams of kRngPixels pixels
 struct WaveLds {
   float4* r0;   // c.x c.y c.z | det(A0) = det(b,e1,e2)
   float4* r1;   // p.x p.y p.z | q.x        p = cof(b,e2), q = cof(e1,b)
@@ -75,104 +90,145 @@ __device__ __forceinline__ WaveLds wave_lds(char* base) {
   return L;
 }
 
-// Number of the 64 jittered shadow rays (lane = sample) from surface point j of the current task
-// towards the light that are NOT blocked: kernels.cl:243-311 evaluated for 64 samples at once.
-//   dminlen, dk : lower bound of |d| over the jitter box and sqrt(radius_sq)*(1+slack), for the cull
-//   sph_maybe   : false when no sample's ray can reach a shadow-casting sphere
-template <bool CULL, bool COUNT>
-__device__ __forceinline__ int wave_unshadowed(const FrameParams& P, const TriLane& T, const WaveLds& L, int lane, int ns,
-                                               int j, float dminlen, float dk, bool sph_maybe, f3 jit, Work& wk) {
+// ---- the reference's sample test, lane = sample ----------------------------------------------------
+// One triangle against the 64 jittered rays of one surface point: kernels.cl:249-275.  c, nA0 = det(A0),
+// p = cof(b,e2), q = cof(e1,b) are wave-uniform values held in VGPRs.  Returns the lanes that hit.
+template <bool COUNT>
+__device__ __forceinline__ unsigned long long sample_test(f3 d, f3 nd, float radius_sq, f3 c, float nA0, f3 p, f3 q,
+                                                          unsigned long long shadowed, Work& wk) {
+  const float detA = detc(nd, c);
+  float rr = rcp_newton(detA, 1);          // == 1.0f/detA, or NaN when detA is 0/denormal/inf (rt_math.h)
+  float t = nA0 * rr;
+  f3 dv = t * d;
+  float dist = dv.x * dv.x + dv.y * dv.y + dv.z * dv.z;
+  // first stage, :266.  The negated compares are also true for NaN, so a lane whose reciprocal needs the
+  // division fallback reaches the second stage, where it is recomputed exactly.
+  unsigned long long pass = ballot(!(t < 0.0f)) & ballot(!(dist >= radius_sq));
+  if (COUNT) wk.v[1] += 1;
+  if ((pass & ~shadowed) == 0ull) return 0ull;
+  if (COUNT) wk.v[2] += 1;
+  if (ballot(rr != rr) != 0ull) {                                    // rare: reciprocal outside v_rcp's range
+    rr = 1.0f / detA;
+    t = nA0 * rr;
+    dv = t * d;
+    dist = dv.x * dv.x + dv.y * dv.y + dv.z * dv.z;
+    pass = ballot(t >= 0) & ballot(dist < radius_sq);
+  }
+  const float u = detc(nd, p) * rr;
+  const float v = detc(nd, q) * rr;
+  return pass & ballot(u >= 0) & ballot(v >= 0) & ballot((u + v) <= 1);   // :272
+}
+
+// ---- brute force (CULL = false): every triangle for every surface point ---------------------------
+template <bool COUNT>
+__device__ __forceinline__ int wave_unshadowed_all(const FrameParams& P, const TriLane& T, const WaveLds& L, int lane,
+                                                   int ns, int j, f3 jit, Work& wk) {
   const float4 h0 = L.h0[j], h1 = L.h1[j];                 // LDS broadcasts
   const f3 start = mk(h0.x, h0.y, h0.z), dir = mk(h1.x, h1.y, h1.z);
   const float radius_sq = h0.w;
   const f3 d = dir + jit;       // shadow_ray.direction + crush(rand_vec, light_spread), :333
   const f3 nd = -d;
-  // ---- once per surface point, lane i = triangle i -------------------------------------------------
-  unsigned long long cand;
-  {
+  {                             // once per surface point, lane i = triangle i
     const f3 b = start - T.v0;
-    const f3 p = cof(b, T.e2);             // cofactors of det(A1) = det(-d, b, e2), :269
-    const f3 q = cof(T.e1, b);             // cofactors of det(A2) = det(-d, e1, b), :270
-    const float nA0 = detc(b, T.c);        // det(A0), :257-259
-    reinterpret_cast<float*>(&L.r0[lane])[3] = nA0;
+    const f3 p = cof(b, T.e2), q = cof(T.e1, b);
+    reinterpret_cast<float*>(&L.r0[lane])[3] = detc(b, T.c);
     L.r1[lane] = make_float4(p.x, p.y, p.z, q.x);
     L.r2[lane] = make_float2(q.y, q.z);
-    bool keep = lane < ns;
-    if (CULL) {
-      // Interval bounds of the three determinants over the jitter box d = dir + [-h,h]^3.  hh >= h plus
-      // every rounding error of the per-sample evaluation (see DESIGN.md "exact culling").
-      const float hh = h1.w;
-      const f3 md = -dir;
-      const float D0 = detc(md, T.c), N1 = detc(md, p), N2 = detc(md, q);
-      const float aD = fabsf(D0);
-      const float Delta = hh * T.c1;
-      const bool robust = aD > Delta + 1e-30f;           // every sample's det(A) has D0's sign and is normal
-      const float sg = copysignf(1.0f, D0);
-      const float tn = sg * nA0, un = sg * N1, vn = sg * N2;
-      const float hp = hh * (fabsf(p.x) + fabsf(p.y) + fabsf(p.z));
-      const float hq = hh * (fabsf(q.x) + fabsf(q.y) + fabsf(q.z));
-      const float hiD = aD + Delta;
-      const bool cS = tn < -1e-18f;                                  // t < 0 for every sample
-      const bool cR = fabsf(nA0) * dminlen > hiD * dk;               // |t*d|^2 >= radius_sq for every sample
-      const bool cU = un < -(hp + 1e-18f);                           // u < 0 for every sample
-      const bool cV = vn < -(hq + 1e-18f);                           // v < 0 for every sample
-      const bool cW = (un + vn) - (hp + hq) > hiD * 1.000004f;       // u+v > 1 wherever u,v >= 0
-      keep = keep && !(robust && (cS || cR || cU || cV || cW));
-    }
-    cand = ballot(keep);
-    if (COUNT) { wk.v[0] += 1; wk.v[4] += (unsigned)(ns - __popcll(cand)); }
+    if (COUNT) wk.v[0] += 1;
   }
   __builtin_amdgcn_wave_barrier();
-  // ---- 64 samples against each candidate triangle ---------------------------------------------------
-  // Lane predicates are kept as explicit 64-bit wave masks: each ballot below is ONE v_cmp writing an
-  // SGPR pair, and all the and/or logic runs on the scalar unit.
   unsigned long long shadowed = 0ull;
-  if (cand != 0ull) {
-    int i = __builtin_ctzll(cand);
-    cand &= cand - 1ull;
-    float4 r0 = L.r0[i];
-    for (;;) {
-      const int inext = cand ? __builtin_ctzll(cand) : 0;
-      const float4 nxt = L.r0[inext];          // prefetch the next candidate's record
-      const float detA = detc(nd, mk(r0.x, r0.y, r0.z));
-      float rr = rcp_newton(detA, 1);          // == 1.0f/detA, or NaN when detA is 0/denormal/inf (rt_math.h)
-      float t = r0.w * rr;
-      f3 dv = t * d;
-      float dist = dv.x * dv.x + dv.y * dv.y + dv.z * dv.z;
-      // first stage, :266.  The negated compares are also true for NaN, so a lane whose reciprocal needs
-      // the division fallback reaches the second stage, where it is recomputed exactly.
-      unsigned long long pass = ballot(!(t < 0.0f)) & ballot(!(dist >= radius_sq));
-      if (COUNT) wk.v[1] += 1;
-      if ((pass & ~shadowed) != 0ull) {                                // wave-uniform second stage
-        if (COUNT) wk.v[2] += 1;
-        if (ballot(rr != rr) != 0ull) {                                // rare: reciprocal outside v_rcp's range
-          rr = 1.0f / detA;
-          t = r0.w * rr;
-          dv = t * d;
-          dist = dv.x * dv.x + dv.y * dv.y + dv.z * dv.z;
-          pass = ballot(t >= 0) & ballot(dist < radius_sq);
-        }
-        const float4 r1 = L.r1[i];
-        const float2 r2 = L.r2[i];
-        const float u = detc(nd, mk(r1.x, r1.y, r1.z)) * rr;
-        const float v = detc(nd, mk(r1.w, r2.x, r2.y)) * rr;
-        shadowed |= pass & ballot(u >= 0) & ballot(v >= 0) & ballot((u + v) <= 1);   // :272
-        if (shadowed == ~0ull) break;                                  // every sample blocked: any-hit early-out
-      }
-      if (cand == 0ull) break;
-      cand &= cand - 1ull;
-      i = inext;
-      r0 = nxt;
-    }
+  float4 r0 = L.r0[0];
+  for (int i = 0; i < ns; ++i) {
+    const float4 nxt = L.r0[i + 1 < 64 ? i + 1 : 63];     // prefetch the next record
+    const float4 r1 = L.r1[i];
+    const float2 r2 = L.r2[i];
+    shadowed |= sample_test<COUNT>(d, nd, radius_sq, mk(r0.x, r0.y, r0.z), r0.w, mk(r1.x, r1.y, r1.z),
+                                   mk(r1.w, r2.x, r2.y), shadowed, wk);
+    if (shadowed == ~0ull) break;                          // every sample blocked: any-hit early-out
+    r0 = nxt;
   }
   __builtin_amdgcn_wave_barrier();
   bool sh = (shadowed >> lane) & 1ull;
-  if (sph_maybe && shadowed != ~0ull) {
+  if (P.nsph > 0 && shadowed != ~0ull) {
     Work unused;
     if (COUNT) wk.v[3] += 1;
     if (!sh) sh = shadow_spheres<false>(P, start, d, radius_sq, unused);
   }
   return __popcll(ballot(!sh));
+}
+
+// ---- interval bounds ----------------------------------------------------------------------------------
+// Level 1 (lane = triangle): can ANY shadow sample of ANY lit surface point of the current task hit this
+// triangle (`clear` = no), and do ALL of them hit it (`all_blocked`)?
+//   s0, D0 : start / dir of a reference surface point;  es, ed : max |component| deviation of the other
+//            points' start / dir from it;  hh : jitter half-width incl. rounding slack (max over points);
+//   dlen_min/max : range of |dir| over the points.
+struct Bound { bool clear, all_blocked; };
+__device__ __forceinline__ Bound task_bound(const TriLane& T, f3 s0, f3 D0, float es, float ed, float hh,
+                                            float dlen_min, float dlen_max) {
+  const f3 b0 = s0 - T.v0;
+  const float binf = fmaxf(fmaxf(fabsf(b0.x), fabsf(b0.y)), fabsf(b0.z));
+  const float eb = 1.001f * es + 1e-6f * (binf + es);              // |b - b0| per component, any point
+  const float nA0 = detc(b0, T.c);
+  const f3 p0 = cof(b0, T.e2), q0 = cof(T.e1, b0);
+  const float p1 = norm1(p0), q1 = norm1(q0);
+  const float ep1 = 2.002f * eb * T.e2_1, eq1 = 2.002f * eb * T.e1_1;   // sum_k |p_k - p0_k|, |q_k - q0_k|
+  const f3 md = -D0;
+  const float A0 = detc(md, T.c), N1 = detc(md, p0), N2 = detc(md, q0);
+  const float edd = 1.001f * ed + hh;                               // |d - D0| per component, any point, any sample
+  const float E0 = eb * T.c1 * 1.0001f;
+  const float EA = edd * T.c1 * 1.0001f;
+  const float E1 = (dlen_max * ep1 + edd * (p1 + ep1)) * 1.0001f;
+  const float E2 = (dlen_max * eq1 + edd * (q1 + eq1)) * 1.0001f;
+  const float aD = fabsf(A0), hiD = aD + EA, loD = aD - EA;
+  const bool robust = aD > EA + 1e-30f;
+  const float sg = copysignf(1.0f, A0);
+  const float tn = sg * nA0, un = sg * N1, vn = sg * N2;
+  const float dmin = fmaxf(dlen_min - 1.7321f * hh, 0.0f), dmax = dlen_max + 1.7321f * hh;
+  // A sample can only hit if det(A), det(A0), det(A1), det(A2) share one sign (t,u,v >= 0): cull when
+  // neither the all-positive nor the all-negative combination is possible.  No condition on det(A): this
+  // also settles rays that are nearly parallel to the triangle's plane, where det(A) changes sign.
+  const bool can_pos = (A0 + EA > 0.0f) && (nA0 + E0 > -1e-18f) && (N1 + E1 > -1e-18f) && (N2 + E2 > -1e-18f);
+  const bool can_neg = (A0 - EA < 0.0f) && (nA0 - E0 < 1e-18f) && (N1 - E1 < 1e-18f) && (N2 - E2 < 1e-18f);
+  const bool cR = (fabsf(nA0) - E0) * dmin > hiD * (dlen_max * 1.000004f);   // |t d|^2 >= radius_sq everywhere
+  const bool cW = fabsf(N1 + N2) - (E1 + E2) > hiD * 1.000004f;              // u+v > 1 wherever u,v >= 0
+  Bound r;
+  r.clear = (!can_pos && !can_neg) || cR || cW;
+  r.all_blocked = robust && (tn - E0 > 1e-18f) && (un - E1 > 1e-18f) && (vn - E2 > 1e-18f) &&
+                  ((un + vn) + (E1 + E2) < loD * 0.999996f) &&
+                  ((fabsf(nA0) + E0) * dmax < loD * (dlen_min * 0.999996f));
+  return r;
+}
+
+// Level 2 (lane = surface point): the same question for ONE point (this lane's) and a wave-uniform
+// triangle.  hh >= h plus every rounding error of the per-sample evaluation; every sample's det(A) lies in
+// D0 +- hh*|c|_1, det(A1) in N1 +- hh*|p|_1, det(A2) in N2 +- hh*|q|_1 (they are linear in the direction).
+__device__ __forceinline__ Bound point_bound(f3 start, f3 dir, float hh, float dlen, float dminlen, float dk,
+                                             f3 v0, f3 e1, f3 e2, f3 c) {
+  const f3 b = start - v0;
+  const f3 p = cof(b, e2), q = cof(e1, b);
+  const float nA0 = detc(b, c);
+  const f3 md = -dir;
+  const float D0 = detc(md, c), N1 = detc(md, p), N2 = detc(md, q);
+  const float aD = fabsf(D0);
+  const float Delta = hh * norm1(c);
+  const bool robust = aD > Delta + 1e-30f;           // every sample's det(A) has D0's sign and is normal
+  const float sg = copysignf(1.0f, D0);
+  const float tn = sg * nA0, un = sg * N1, vn = sg * N2;
+  const float hp = hh * norm1(p), hq = hh * norm1(q);
+  const float hiD = aD + Delta, loD = aD - Delta;
+  // sign consistency of det(A), det(A0), det(A1), det(A2) (see task_bound); det(A0) is exact here
+  const bool can_pos = (D0 + Delta > 0.0f) && (nA0 > -1e-18f) && (N1 + hp > -1e-18f) && (N2 + hq > -1e-18f);
+  const bool can_neg = (D0 - Delta < 0.0f) && (nA0 < 1e-18f) && (N1 - hp < 1e-18f) && (N2 - hq < 1e-18f);
+  const bool cR = fabsf(nA0) * dminlen > hiD * dk;               // |t*d|^2 >= radius_sq for every sample
+  const bool cW = fabsf(N1 + N2) - (hp + hq) > hiD * 1.000004f;  // u+v > 1 wherever u,v >= 0
+  Bound r;
+  r.clear = (!can_pos && !can_neg) || cR || cW;
+  r.all_blocked = robust && (tn > 1e-18f) && (un - hp > 1e-18f) && (vn - hq > 1e-18f) &&
+                  ((un + vn) + (hp + hq) < loD * 0.999996f) &&
+                  (fabsf(nA0) * (dlen + 1.7321f * hh) < loD * (dlen * 0.999996f));
+  return r;
 }
 
 // Can any jittered ray from `start` towards `dir` (+- jitter of half-width hh per axis) touch a
@@ -191,6 +247,37 @@ __device__ __forceinline__ bool spheres_maybe(const FrameParams& P, f3 start, f3
     maybe = maybe || !miss;
   }
   return maybe;
+}
+
+// Level 3 (lane = sample): surface point j against the triangles of K whose bit is set in `need`.
+template <bool COUNT>
+__device__ __forceinline__ int wave_unshadowed_some(const FrameParams& P, const LdsScene& S, const int* sidx,
+                                                    const WaveLds& L, int lane, int j, unsigned long long K,
+                                                    unsigned long long need, bool sph_maybe, f3 jit, Work& wk) {
+  const float4 h0 = L.h0[j], h1 = L.h1[j];                 // LDS broadcasts
+  const f3 start = mk(h0.x, h0.y, h0.z), dir = mk(h1.x, h1.y, h1.z);
+  const float radius_sq = h0.w;
+  const f3 d = dir + jit;       // shadow_ray.direction + crush(rand_vec, light_spread), :333
+  const f3 nd = -d;
+  if (COUNT) wk.v[0] += 1;
+  unsigned long long shadowed = 0ull;
+  int pos = 0;
+  for (unsigned long long kk = K; kk != 0ull; kk &= kk - 1ull, ++pos) {
+    if (((need >> pos) & 1ull) == 0ull) continue;
+    const int ti = sidx[__builtin_ctzll(kk)];
+    // sample-independent terms of (point j, triangle ti): wave-uniform inputs, same arithmetic as :251-270
+    const f3 v0 = xyz(S.v0[ti]), e1 = xyz(S.e1[ti]), e2 = xyz(S.e2[ti]), c = xyz(S.c[ti]);
+    const f3 b = start - v0;
+    shadowed |= sample_test<COUNT>(d, nd, radius_sq, c, detc(b, c), cof(b, e2), cof(e1, b), shadowed, wk);
+    if (shadowed == ~0ull) break;                          // every sample blocked: any-hit early-out
+  }
+  bool sh = (shadowed >> lane) & 1ull;
+  if (sph_maybe && shadowed != ~0ull) {
+    Work unused;
+    if (COUNT) wk.v[3] += 1;
+    if (!sh) sh = shadow_spheres<false>(P, start, d, radius_sq, unused);
+  }
+  return __popcll(ballot(!sh));
 }
 
 }  // namespace
@@ -225,13 +312,14 @@ __global__ __launch_bounds__(256) void rt_draw_wave(const FrameParams P) {
   const int GP = PT < kRngPixels ? PT : kRngPixels;                   // pixels per RNG group
   const f3 light = mk(P.light[0], P.light[1], P.light[2]);
   const float hbox = P.spread / 2.f;                                  // |crush()| <= range/2, :51
+  const unsigned long long tri_lanes = ns == 64 ? ~0ull : ((1ull << ns) - 1ull);
 
   TriLane T;
   {
     const int ti = sidx[lane < ns ? lane : 0];
     T.v0 = xyz(S.v0[ti]); T.e1 = xyz(S.e1[ti]); T.e2 = xyz(S.e2[ti]); T.c = xyz(S.c[ti]);
-    T.c1 = fabsf(T.c.x) + fabsf(T.c.y) + fabsf(T.c.z);
-    L.r0[lane] = make_float4(T.c.x, T.c.y, T.c.z, 0.f);       // static part of record 0
+    T.c1 = norm1(T.c); T.e1_1 = norm1(T.e1); T.e2_1 = norm1(T.e2);
+    if (!CULL) L.r0[lane] = make_float4(T.c.x, T.c.y, T.c.z, 0.f);   // static part of record 0
   }
 
   f3 outc = mk(0.f, 0.f, 0.f);
@@ -258,25 +346,68 @@ __global__ __launch_bounds__(256) void rt_draw_wave(const FrameParams P) {
     const f3 start = ray.P + 0.0001f * dir;
     const float radius_sq = dir.x * dir.x + dir.y * dir.y + dir.z * dir.z;
     const float term = (16.0f * fmaxf(dot3(dir, ray.N), 0.0f)) / (4.0f * 3.14159274f * radius_sq);
-    // bounds used by the cull (never by the shading): |dir|, jitter half-width with rounding slack
-    const float dlen = sqrtf(radius_sq);
-    const float hh = 1.002f * hbox + 2e-6f * (dlen + hbox);
-    float dminlen = dlen - 1.7321f * hh;
-    if (!(radius_sq > 1e-18f) || !(dminlen > 0.0f)) dminlen = 0.0f;   // disables the distance rule
-    const float dk = dlen * 1.000004f;
-    const unsigned long long sphmask = CULL ? ballot(lit && P.nsph > 0 && spheres_maybe(P, start, dir, dlen, hh))
-                                            : (P.nsph > 0 ? ~0ull : 0ull);
     __builtin_amdgcn_wave_barrier();
     L.h0[lane] = make_float4(start.x, start.y, start.z, radius_sq);
-    L.h1[lane] = make_float4(dir.x, dir.y, dir.z, hh);
+    L.h1[lane] = make_float4(dir.x, dir.y, dir.z, 0.f);
     __builtin_amdgcn_wave_barrier();
 
-    // ---- phase 3: wave-wide shadow test, one lit lane at a time ---------------------------------------
-    int unshadowed = 0;
-    const unsigned long long litmask = ballot(lit);
+    // ---- phase 3: shadows of the lit surface points ---------------------------------------------------
+    int unshadowed = 64;                        // samples of this lane's surface point that reach the light
+    unsigned long long work = ballot(lit);      // lanes whose samples must really be tested (level 3)
+    unsigned long long K = tri_lanes, need = ~0ull, sphmask = P.nsph > 0 ? ~0ull : 0ull;
+    if (CULL && work != 0ull) {
+      // bounds used by the cull (never by the shading): |dir|, jitter half-width with rounding slack
+      const float dlen = sqrtf(radius_sq);
+      const float hh = 1.002f * hbox + 2e-6f * (dlen + hbox);
+      float dminlen = dlen - 1.7321f * hh;
+      const bool sane = lit && (radius_sq > 1e-18f) && (radius_sq < 1e30f);
+      if (!sane || !(dminlen > 0.0f)) dminlen = 0.0f;                  // disables the distance rule
+      const float dk = dlen * 1.000004f;
+      sphmask = ballot(lit && P.nsph > 0 && spheres_maybe(P, start, dir, dlen, hh));
+      // level 1: all lit points of the task at once, lane = triangle
+      bool task_blocked = false;
+      {
+        const int jr = __builtin_ctzll(work);
+        const f3 s0 = mk(rl(start.x, jr), rl(start.y, jr), rl(start.z, jr));
+        const f3 D0 = mk(rl(dir.x, jr), rl(dir.y, jr), rl(dir.z, jr));
+        const f3 ds = start - s0, dd = dir - D0;
+        const float es = wave_max(lit ? fmaxf(fmaxf(fabsf(ds.x), fabsf(ds.y)), fabsf(ds.z)) : 0.0f);
+        const float ed = wave_max(lit ? fmaxf(fmaxf(fabsf(dd.x), fabsf(dd.y)), fabsf(dd.z)) : 0.0f);
+        const float dlen_max = wave_max(lit ? dlen : 0.0f);
+        const float dlen_min = wave_min(lit ? dlen : 3.0e38f);
+        const bool all_sane = ballot(lit && !sane) == 0ull;
+        if (all_sane && es < 1e30f && ed < 1e30f) {                    // finite, non-degenerate
+          const float hh_task = 1.002f * hbox + 2e-6f * (dlen_max + hbox);
+          const Bound tb = task_bound(T, s0, D0, es, ed, hh_task, dlen_min, dlen_max);
+          K = tri_lanes & ~ballot(tb.clear);
+          task_blocked = (tri_lanes & ballot(tb.all_blocked)) != 0ull;
+        }
+      }
+      if (task_blocked) {
+        unshadowed = 0; work = 0ull;
+        if (COUNT) xw.v[5] += 1;
+      } else {
+        // level 2: per surface point, lane = point, over the triangles K that survived level 1
+        bool blocked = false;
+        need = 0ull;
+        int pos = 0;
+        for (unsigned long long kk = K; kk != 0ull; kk &= kk - 1ull, ++pos) {
+          const int ti = sidx[__builtin_ctzll(kk)];
+          const Bound pb = point_bound(start, dir, hh, dlen, dminlen, dk, xyz(S.v0[ti]), xyz(S.e1[ti]), xyz(S.e2[ti]),
+                                       xyz(S.c[ti]));
+          if (!pb.clear || !sane) need |= 1ull << pos;
+          blocked = blocked || (sane && pb.all_blocked);
+        }
+        if (blocked) unshadowed = 0;
+        work = ballot(lit && !blocked && (need != 0ull || ((sphmask >> lane) & 1ull) != 0ull));
+        if (COUNT) { xw.v[4] += (unsigned)__popcll(ballot(lit && !blocked && need == 0ull)); if (work == 0ull) xw.v[5] += 1; }
+      }
+    }
+
+    // level 3 / brute force: the reference's sample test, one surface point at a time
     const int GL = GP * aa;                     // lanes per RNG group
-    for (int g = 0; g * GL < 64; ++g) {
-      const unsigned long long gm = (litmask >> (g * GL)) & (GL == 64 ? ~0ull : ((1ull << GL) - 1ull));
+    for (int g = 0; g * GL < 64 && work != 0ull; ++g) {
+      const unsigned long long gm = (work >> (g * GL)) & (GL == 64 ? ~0ull : ((1ull << GL) - 1ull));
       if (gm == 0ull) continue;
       // xorshift streams of the GP pixels of this group: lane c -> (pixel c/3, component c%3), :319,:331
       if (lane < 3 * GP) {
@@ -299,7 +430,14 @@ __global__ __launch_bounds__(256) void rt_draw_wave(const FrameParams P) {
         while (pm != 0ull) {
           const int j = base + __builtin_ctzll(pm);
           pm &= pm - 1ull;
-          const int cnt = wave_unshadowed<CULL, COUNT>(P, T, L, lane, ns, j, rl(dminlen, j), rl(dk, j), (sphmask >> j) & 1ull, jit, xw);
+          int cnt;
+          if (CULL) {
+            const unsigned long long nj = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(need >> 32), j) << 32) |
+                                          (unsigned)__builtin_amdgcn_readlane((int)need, j);
+            cnt = wave_unshadowed_some<COUNT>(P, S, sidx, L, lane, j, K, nj, (sphmask >> j) & 1ull, jit, xw);
+          } else {
+            cnt = wave_unshadowed_all<COUNT>(P, T, L, lane, ns, j, jit, xw);
+          }
           if (lane == j) unshadowed = cnt;
         }
       }
@@ -333,7 +471,7 @@ __global__ __launch_bounds__(256) void rt_draw_wave(const FrameParams P) {
   }
 
   if (COUNT) {                               // wave-uniform counters: lane 0 publishes them
-    if (lane == 0) for (int q = 0; q < 5; ++q) if (xw.v[q]) atomicAdd(&P.counters[q], xw.v[q]);
+    if (lane == 0) for (int q = 0; q < 6; ++q) if (xw.v[q]) atomicAdd(&P.counters[q], xw.v[q]);
     return;
   }
   // ---- store: 64 consecutive pixels, one coalesced access per wave ------------------------------------

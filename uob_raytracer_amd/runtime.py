@@ -195,7 +195,7 @@ class RayTracer:
         out = (C.c_uint64 * 8)()
         _check(lib().rt_count_executed(self._h, _fp(rot), _fp(cam), _fp(light), C.c_float(focal), out))
         keys = ("surface_points", "stage1_wave_iterations", "stage2_wave_iterations", "sphere_wave_evaluations",
-                "culled_pairs")
+                "culled_pairs", "tasks_resolved_whole")
         return {k: int(out[i]) for i, k in enumerate(keys)}
 
     def last_kernel_ms(self):
