@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -32,6 +33,7 @@ void set_error(const char* fmt, ...) {
 
 void launch_generic(const FrameParams& P, bool count, hipStream_t stream);
 void launch_wave(const FrameParams& P, bool cull, bool count, hipStream_t stream);
+void launch_wave_prof(const FrameParams& P, hipStream_t stream);
 bool wave_kernel_supports(const FrameParams& P);
 
 }  // namespace uobrt
@@ -183,6 +185,7 @@ static void fill_params(const rt_ctx* c, const float rot[12], const float cam[3]
   P->owned_rows = c->owned_rows;
   P->sy = (float)g.aa_x / (float)g.aa_y;
   P->n_shadow = c->n_shadow;
+  { const char* e = getenv("UOB_RT_DEBUG_STOP"); P->debug_stop = e ? atoi(e) : 0; }
   for (int i = 0; i < g.num_spheres; ++i) {
     P->sph[i].cx = g.spheres[i].center[0]; P->sph[i].cy = g.spheres[i].center[1]; P->sph[i].cz = g.spheres[i].center[2];
     P->sph[i].r2 = g.spheres[i].radius_sq;
@@ -265,7 +268,8 @@ int rt_count_executed(rt_ctx* c, const float rot[12], const float cam[3], const 
   P.counters = c->d_counters;
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(rt_work), c->stream));
-  launch_wave(P, !(c->cfg.flags & RT_FLAG_NO_CULL), true, c->stream);
+  if (getenv("UOB_RT_PHASE_PROFILE")) launch_wave_prof(P, c->stream);   // diagnostic: s_memtime per phase
+  else launch_wave(P, !(c->cfg.flags & RT_FLAG_NO_CULL), true, c->stream);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(out, c->d_counters, sizeof(rt_work), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));

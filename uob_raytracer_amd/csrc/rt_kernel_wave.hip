@@ -47,13 +47,19 @@ __device__ __forceinline__ float rl(float v, int lane) {
 __device__ __forceinline__ float shfl(float v, int lane) { return __shfl(v, lane, 64); }
 __device__ __forceinline__ unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ float norm1(f3 a) { return fabsf(a.x) + fabsf(a.y) + fabsf(a.z); }
+// Wave-wide reductions.  The result is the same in every lane; readfirstlane tells the compiler so
+// (otherwise everything derived from it — the candidate masks, the loops over them — is treated as
+// divergent and kept in VGPRs with exec-mask loops).
+__device__ __forceinline__ float uniform(float v) {
+  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
 __device__ __forceinline__ float wave_max(float v) {
   for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-  return v;
+  return uniform(v);
 }
 __device__ __forceinline__ float wave_min(float v) {
   for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
-  return v;
+  return uniform(v);
 }
 
 // Per-lane registers of a "triangle lane" (lane i < ns holds shadow-casting triangle i)
@@ -77,16 +83,20 @@ struct WaveLds {
   float4* h1;   // dir.xyz   | hh (jitter half-width incl. rounding slack)
   uint32_t* rng;
 };
-constexpr int kWaveLdsBytes = 64 * (16 + 16 + 8) + 64 * 32 + kRngPixels * kRngStride * 4;
+// the r0..r2 records exist only in the brute-force build
+__host__ __device__ constexpr int wave_lds_bytes(bool cull) {
+  return (cull ? 0 : 64 * (16 + 16 + 8)) + 64 * 32 + kRngPixels * kRngStride * 4;
+}
 
-__device__ __forceinline__ WaveLds wave_lds(char* base) {
+__device__ __forceinline__ WaveLds wave_lds(char* base, bool cull) {
   WaveLds L;
   L.r0 = reinterpret_cast<float4*>(base);
   L.r1 = reinterpret_cast<float4*>(base + 64 * 16);
   L.r2 = reinterpret_cast<float2*>(base + 64 * 32);
-  L.h0 = reinterpret_cast<float4*>(base + 64 * 40);
-  L.h1 = reinterpret_cast<float4*>(base + 64 * 56);
-  L.rng = reinterpret_cast<uint32_t*>(base + 64 * 72);
+  if (!cull) base += 64 * 40;
+  L.h0 = reinterpret_cast<float4*>(base);
+  L.h1 = reinterpret_cast<float4*>(base + 64 * 16);
+  L.rng = reinterpret_cast<uint32_t*>(base + 64 * 32);
   return L;
 }
 
@@ -231,6 +241,25 @@ __device__ __forceinline__ Bound point_bound(f3 start, f3 dir, float hh, float d
   return r;
 }
 
+// Primary rays of one task (lane = triangle i < n): can ANY of the task's rays hit this triangle?
+// The rays leave the camera through the sub-pixel rectangle [wc +- (hx,hy)] x {focal}; before
+// normalisation their directions are du = R w, i.e. duc +- eu per component, and every determinant of
+// the test is linear in the direction, so the sign/ratio conditions can be checked on du (they are
+// invariant under the positive scale 1/|du|).  slack covers the roundings of R w, of the normalisation
+// and of the per-ray determinant evaluation (each a few 2^-24 relative to |du|_max * |cofactors|_1).
+__device__ __forceinline__ bool primary_clear(f3 duc, f3 eu, float dumax, f3 c, float nA0cam, f3 pc, f3 qc) {
+  const f3 md = -duc;
+  const float Ac = detc(md, c), N1 = detc(md, pc), N2 = detc(md, qc);
+  const float sl = 4e-6f * dumax;
+  const float EA = eu.x * fabsf(c.x) + eu.y * fabsf(c.y) + eu.z * fabsf(c.z) + sl * norm1(c);
+  const float E1 = eu.x * fabsf(pc.x) + eu.y * fabsf(pc.y) + eu.z * fabsf(pc.z) + sl * norm1(pc);
+  const float E2 = eu.x * fabsf(qc.x) + eu.y * fabsf(qc.y) + eu.z * fabsf(qc.z) + sl * norm1(qc);
+  const bool can_pos = (Ac + EA > 0.0f) && (nA0cam > -1e-18f) && (N1 + E1 > -1e-30f) && (N2 + E2 > -1e-30f);
+  const bool can_neg = (Ac - EA < 0.0f) && (nA0cam < 1e-18f) && (N1 - E1 < 1e-30f) && (N2 - E2 < 1e-30f);
+  const bool cW = fabsf(N1 + N2) - (E1 + E2) > (fabsf(Ac) + EA) * 1.000004f;
+  return (!can_pos && !can_neg) || cW;
+}
+
 // Can any jittered ray from `start` towards `dir` (+- jitter of half-width hh per axis) touch a
 // shadow-casting sphere?  Conservative: the line misses sphere (c,R) when |L x d| > R |d|; bound both
 // sides over the jitter box and leave 0.2 % + rounding slack for the reference's discriminant (:285).
@@ -282,27 +311,46 @@ __device__ __forceinline__ int wave_unshadowed_some(const FrameParams& P, const 
 
 }  // namespace
 
-// Grid: x = ceil(W/64) row segments, y = ceil(owned_rows/4); block = 256 threads = 4 waves = 4 rows.
-template <bool CULL, bool COUNT>
-__global__ __launch_bounds__(256) void rt_draw_wave(const FrameParams P) {
+// Grid: x = ceil(W/64) row segments, y = ceil(owned_rows/kWavesPerBlock); one wave per 64-pixel segment.
+// (one wave per workgroup measured 20 % slower than four: 22.1 vs 18.3 ms on the headline frame)
+#ifndef RT_WAVES_PER_BLOCK
+#define RT_WAVES_PER_BLOCK 4
+#endif
+constexpr int kWavesPerBlock = RT_WAVES_PER_BLOCK;
+// PROF builds (diagnostic only, never timed): per-phase s_memtime shares, summed over waves, in counters[0..7]
+#define RT_STAMP(slot)                                                              \
+  if (PROF) {                                                                       \
+    unsigned long long now_;                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                              \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_) :: "memory"); \
+    __builtin_amdgcn_sched_barrier(0);                                              \
+    prof[slot] += now_ - tlast;                                                     \
+    tlast = now_;                                                                   \
+  }
+template <bool CULL, bool COUNT, bool PROF = false>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void rt_draw_wave(const FrameParams P) {
+  unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
   extern __shared__ float4 lds[];
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int n = P.n, ns = P.n_shadow;
 
   // ---- stage the triangle list once per workgroup ---------------------------------------------------
-  stage_triangles(P, lds, tid, 256);
+  stage_triangles(P, lds, tid, 64 * kWavesPerBlock);
   int* sidx = reinterpret_cast<int*>(lds + kLdsRecords * n);          // shadow-casting triangles, in order
   if (wave == 0) {                                                    // n <= 64 on this path (supports())
     const bool casts = (lane < n) && (P.colors[lane < n ? lane : 0].w != -1.0f);   // glass casts no shadow, :247
     const unsigned long long m = ballot(casts);
     if (casts) sidx[__popcll(m & ((1ull << lane) - 1ull))] = lane;
   }
+  RT_STAMP(7)                               // 7: staging work before the workgroup barrier
   __syncthreads();
-  const WaveLds L = wave_lds(reinterpret_cast<char*>(sidx + ((n + 3) & ~3)) + wave * kWaveLdsBytes);
+  const WaveLds L = wave_lds(reinterpret_cast<char*>(sidx + ((n + 3) & ~3)) + wave * wave_lds_bytes(CULL), CULL);
 
-  const int lr = blockIdx.y * 4 + wave;
+  const int lr = blockIdx.y * kWavesPerBlock + wave;
   if (lr >= P.owned_rows) return;                                     // whole wave; no block barrier follows
+  if (P.debug_stop == 1) { if (lane == 0) P.out_argb[(size_t)lr * P.W + blockIdx.x * 64] = sidx[0]; return; }
   const LdsScene S = lds_scene(lds, n);
   const int x0 = blockIdx.x * 64;
   const int y = band_global_row(lr, P.band_rows, P.band_index, P.band_count);
@@ -322,6 +370,7 @@ __global__ __launch_bounds__(256) void rt_draw_wave(const FrameParams P) {
     if (!CULL) L.r0[lane] = make_float4(T.c.x, T.c.y, T.c.z, 0.f);   // static part of record 0
   }
 
+  RT_STAMP(0)                               // 0: staging + set-up
   f3 outc = mk(0.f, 0.f, 0.f);
   Work wk, xw;                               // xw: executed-work counters of this wave (COUNT builds only)
   if (COUNT) for (int q = 0; q < 8; ++q) xw.v[q] = 0;
@@ -333,14 +382,34 @@ __global__ __launch_bounds__(256) void rt_draw_wave(const FrameParams P) {
     const bool valid = x < P.W;
     Ray ray = primary_ray(P, x, y, a % P.aa_x, a / P.aa_x);
     bool lit = false, secondary = false;
+    unsigned long long Kp = n == 64 ? ~0ull : ((1ull << n) - 1ull);    // triangles a primary ray may hit
+    if (CULL) {
+      const float Xlo = (float)((x0 + k * PT) * P.aa_x) - ((float)P.W * (float)P.aa_x) / 2.0f;
+      const float Ylo = ((float)(y * P.aa_y) - ((float)P.H * (float)P.aa_y) / 2.0f) * P.sy;
+      const float hx = 0.5f * (float)(PT * P.aa_x - 1), hy = 0.5f * (float)(P.aa_y - 1) * P.sy;
+      const f3 wc = mk(Xlo + hx, Ylo + hy, P.focal);
+      const f3 r0 = mk(P.rot[0], P.rot[1], P.rot[2]), r1 = mk(P.rot[4], P.rot[5], P.rot[6]),
+               r2 = mk(P.rot[8], P.rot[9], P.rot[10]);
+      const f3 duc = mk(dot3(r0, wc), dot3(r1, wc), dot3(r2, wc));
+      const f3 eu = mk(1.0001f * (fabsf(r0.x) * hx + fabsf(r0.y) * hy), 1.0001f * (fabsf(r1.x) * hx + fabsf(r1.y) * hy),
+                       1.0001f * (fabsf(r2.x) * hx + fabsf(r2.y) * hy));
+      const float dumax = fmaxf(fmaxf(fabsf(duc.x) + eu.x, fabsf(duc.y) + eu.y), fabsf(duc.z) + eu.z);
+      const int ti = lane < n ? lane : 0;
+      const float4 c4 = S.c[ti];
+      const bool clear = primary_clear(duc, eu, dumax, xyz(c4), c4.w, xyz(S.pc[ti]), xyz(S.qc[ti]));
+      if (dumax < 1e30f) Kp &= ~ballot(clear);
+    }
     if (valid) {
-      closest_hit_primary<false>(S, P, ray, wk);
+      if (CULL) closest_hit_primary_masked(S, P, ray, Kp);
+      else closest_hit_primary<false>(S, P, ray, wk);
       if (ray.tri != -1) {
         // ---- phase 2: mirror / glass bounces (kernels.cl:342-365) -----------------------------------
         if (ray.col.w <= 0.0f) { secondary = true; lit = bounce_to_diffuse<false>(S, P, ray, wk); }
         else lit = true;
       }
     }
+    if (P.debug_stop == 2) { outc = outc + ray.P + mk(lit ? 1.f : 0.f, ray.N.x, ray.col.x); continue; }
+    RT_STAMP(1)                             // 1: primary rays + bounces
     // per-lane light set-up of direct_light, :323-326
     const f3 dir = light - ray.P;
     const f3 start = ray.P + 0.0001f * dir;
@@ -383,6 +452,7 @@ __global__ __launch_bounds__(256) void rt_draw_wave(const FrameParams P) {
           task_blocked = (tri_lanes & ballot(tb.all_blocked)) != 0ull;
         }
       }
+      RT_STAMP(2)                           // 2: light set-up + level 1
       if (task_blocked) {
         unshadowed = 0; work = 0ull;
         if (COUNT) xw.v[5] += 1;
@@ -404,13 +474,15 @@ __global__ __launch_bounds__(256) void rt_draw_wave(const FrameParams P) {
       }
     }
 
+    if (P.debug_stop == 3) { outc = outc + mk((float)unshadowed, (float)__popcll(work), (float)(need & 0xffff) + term); continue; }
+    RT_STAMP(3)                             // 3: level 2
     // level 3 / brute force: the reference's sample test, one surface point at a time
     const int GL = GP * aa;                     // lanes per RNG group
     for (int g = 0; g * GL < 64 && work != 0ull; ++g) {
       const unsigned long long gm = (work >> (g * GL)) & (GL == 64 ? ~0ull : ((1ull << GL) - 1ull));
       if (gm == 0ull) continue;
       // xorshift streams of the GP pixels of this group: lane c -> (pixel c/3, component c%3), :319,:331
-      if (lane < 3 * GP) {
+      if (lane < 3 * GP && P.debug_stop != 5) {
         const int pp = lane / 3, comp = lane % 3;
         const int gid = pixel_global_id(P, x0 + k * PT + g * GP + pp, y);
         const uint32_t seed = comp == 0 ? (uint32_t)gid : (uint32_t)((float)gid * (comp == 1 ? 91.0f : 19.0f));
@@ -421,12 +493,14 @@ __global__ __launch_bounds__(256) void rt_draw_wave(const FrameParams P) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      RT_STAMP(4)                           // 4: xorshift streams
       for (int pp = 0; pp < GP; ++pp) {
         unsigned long long pm = (gm >> (pp * aa)) & (aa == 64 ? ~0ull : ((1ull << aa) - 1ull));
         if (pm == 0ull) continue;
         const uint32_t* src = L.rng + pp * kRngStride + lane * 4;     // lane = sample index
         const f3 jit = mk(crush1(src[0], P.spread), crush1(src[1], P.spread), crush1(src[2], P.spread));
         const int base = g * GL + pp * aa;
+        if (P.debug_stop == 6) { outc = outc + jit; continue; }
         while (pm != 0ull) {
           const int j = base + __builtin_ctzll(pm);
           pm &= pm - 1ull;
@@ -442,8 +516,11 @@ __global__ __launch_bounds__(256) void rt_draw_wave(const FrameParams P) {
         }
       }
       __builtin_amdgcn_wave_barrier();          // scratch is rewritten by the next group
+      RT_STAMP(5)                           // 5: level 3 sample tests
     }
+    RT_STAMP(5)
 
+    if (P.debug_stop == 4) { outc = outc + mk((float)unshadowed, term, ray.col.x); continue; }
     // ---- phase 4: shade lane-parallel (direct_light's sum :335, then :354 / :421-422) ----------------
     f3 contrib = mk(0.f, 0.f, 0.f);
     if (lit) {
@@ -468,6 +545,11 @@ __global__ __launch_bounds__(256) void rt_draw_wave(const FrameParams P) {
       const f3 v = mk(shfl(acc.x, srcl), shfl(acc.y, srcl), shfl(acc.z, srcl));
       if (rel >= 0 && rel < PT) outc = v;
     }
+    RT_STAMP(6)                             // 6: shading + AA sum
+  }
+  if (PROF) {
+    if (lane == 0) for (int q = 0; q < 8; ++q) atomicAdd(&P.counters[q], prof[q]);
+    return;
   }
 
   if (COUNT) {                               // wave-uniform counters: lane 0 publishes them
@@ -489,6 +571,7 @@ template __global__ void rt_draw_wave<false, false>(const FrameParams);
 template __global__ void rt_draw_wave<true, false>(const FrameParams);
 template __global__ void rt_draw_wave<false, true>(const FrameParams);
 template __global__ void rt_draw_wave<true, true>(const FrameParams);
+template __global__ void rt_draw_wave<true, false, true>(const FrameParams);
 
 bool wave_kernel_supports(const FrameParams& P) {
   const int aa = P.aa_x * P.aa_y;
@@ -496,11 +579,22 @@ bool wave_kernel_supports(const FrameParams& P) {
          P.spread >= 0.0f;
 }
 
+static size_t wave_kernel_lds(const FrameParams& P, bool cull) {
+  return (size_t)P.n * kLdsRecords * sizeof(float4) + (size_t)((P.n + 3) & ~3) * sizeof(int) +
+         kWavesPerBlock * (size_t)wave_lds_bytes(cull);
+}
+
+void launch_wave_prof(const FrameParams& P, hipStream_t stream) {
+  const dim3 block(64 * kWavesPerBlock);
+  const dim3 grid((P.W + 63) / 64, (P.owned_rows + kWavesPerBlock - 1) / kWavesPerBlock);
+  const size_t lds_bytes = wave_kernel_lds(P, true);
+  hipLaunchKernelGGL((rt_draw_wave<true, false, true>), grid, block, lds_bytes, stream, P);
+}
+
 void launch_wave(const FrameParams& P, bool cull, bool count, hipStream_t stream) {
-  const dim3 block(256);
-  const dim3 grid((P.W + 63) / 64, (P.owned_rows + 3) / 4);
-  const size_t lds_bytes = (size_t)P.n * kLdsRecords * sizeof(float4) + (size_t)((P.n + 3) & ~3) * sizeof(int) +
-                           4 * (size_t)kWaveLdsBytes;
+  const dim3 block(64 * kWavesPerBlock);
+  const dim3 grid((P.W + 63) / 64, (P.owned_rows + kWavesPerBlock - 1) / kWavesPerBlock);
+  const size_t lds_bytes = wave_kernel_lds(P, cull);
   if (count) {
     if (cull) hipLaunchKernelGGL((rt_draw_wave<true, true>), grid, block, lds_bytes, stream, P);
     else hipLaunchKernelGGL((rt_draw_wave<false, true>), grid, block, lds_bytes, stream, P);

@@ -139,6 +139,36 @@ __device__ void closest_hit_primary(const LdsScene& S, const FrameParams& P, Ray
   closest_spheres<COUNT>(P, ray, current_t, wk);
 }
 
+// closest_hit_primary restricted to the triangles whose bit is set in `mask` (a wave-uniform 64-bit set,
+// n <= 64), visited in increasing index order so that ties on t resolve exactly as in the full loop
+// (strict '<', kernels.cl:120).  The caller guarantees that no lane's ray can hit a triangle outside it.
+__device__ inline void closest_hit_primary_masked(const LdsScene& S, const FrameParams& P, Ray& ray,
+                                                  unsigned long long mask) {
+  float current_t = RT_MAXFLOAT;
+  const f3 nd = -ray.dir;
+  float bu = 0.f, bv = 0.f;
+  int best = -1;
+  for (; mask != 0ull; mask &= mask - 1ull) {
+    const int i = __builtin_ctzll(mask);
+    const float4 c4 = S.c[i];
+    const float detA_recip = rcp_exact(detc(nd, xyz(c4)));
+    const float t = c4.w * detA_recip;
+    const float u = detc(nd, xyz(S.pc[i])) * detA_recip;
+    const float v = detc(nd, xyz(S.qc[i])) * detA_recip;
+    if (t < current_t && u >= 0 && v >= 0 && (u + v) <= 1 && t >= 0) {
+      best = i; bu = u; bv = v; current_t = t;
+    }
+  }
+  if (best >= 0) {
+    ray.tri = best;
+    ray.P = (xyz(S.v0[best]) + bu * xyz(S.e1[best])) + bv * xyz(S.e2[best]);
+    ray.N = xyz(S.nrm[best]);
+    ray.col = S.col[best];
+  }
+  Work wk;
+  closest_spheres<false>(P, ray, current_t, wk);
+}
+
 // Sphere part of the shadow test, kernels.cl:278-307
 template <bool COUNT>
 __device__ __forceinline__ bool shadow_spheres(const FrameParams& P, f3 start, f3 dir, float radius_sq, Work& wk) {

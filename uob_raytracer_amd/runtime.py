@@ -11,7 +11,7 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libuob_rt.so")
+LIB_PATH = os.environ.get("UOB_RT_LIB", os.path.join(_HERE, "libuob_rt.so"))   # override: kernel experiments only
 
 EXPORTS = (
     "rt_abi_version", "rt_last_error", "rt_config_default", "rt_config_owned_rows", "rt_init", "rt_render",
