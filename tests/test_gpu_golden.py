@@ -39,10 +39,11 @@ def subsets():
     return np.load(os.path.join(G, "frames_subsets.npz"))
 
 
+@pytest.mark.parametrize("flags", [0, abi.RT_FLAG_GENERIC_KERNEL])
 @pytest.mark.parametrize("name", sorted(META["frames"]))
-def test_small_frames(name, scene, small):
+def test_small_frames(name, flags, scene, small):
     kw = META["frames"][name]
-    tr = rt.RayTracer(cfg_of(kw), scene)
+    tr = rt.RayTracer(cfg_of(kw, flags=flags), scene)
     for pi, (yaw, pitch, cam, light) in enumerate(POSES):
         argb, rgb = tr.render(rt.rotation_matrix(yaw, pitch), cam, light, focal_for(kw), want_rgb=True)
         assert np.array_equal(argb, small["%s_p%d_argb" % (name, pi)])

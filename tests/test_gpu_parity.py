@@ -30,9 +30,13 @@ CASES = {
 }
 
 
+# every configuration is rendered by all three device paths: the hierarchical wave kernel (default; falls
+# back to the generic kernel by itself where it does not apply, e.g. 3x3 AA), the same kernel testing
+# every triangle (RT_FLAG_NO_CULL) and the one-thread-per-pixel kernel (RT_FLAG_GENERIC_KERNEL)
+@pytest.mark.parametrize("flags", [0, abi.RT_FLAG_NO_CULL, abi.RT_FLAG_GENERIC_KERNEL])
 @pytest.mark.parametrize("name", list(CASES))
-def test_frame_bit_exact_vs_oracle(name, scene, oracle):
-    cfg = abi.make_config(**CASES[name])
+def test_frame_bit_exact_vs_oracle(name, flags, scene, oracle):
+    cfg = abi.make_config(flags=flags, **CASES[name])
     v, n, c = scene.packed()
     tracer = rt.RayTracer(cfg, scene)
     for yaw, pitch, cam, light in POSES:

@@ -103,9 +103,10 @@ __device__ __forceinline__ WaveLds wave_lds(char* base, bool cull) {
 // ---- the reference's sample test, lane = sample ----------------------------------------------------
 // One triangle against the 64 jittered rays of one surface point: kernels.cl:249-275.  c, nA0 = det(A0),
 // p = cof(b,e2), q = cof(e1,b) are wave-uniform values held in VGPRs.  Returns the lanes that hit.
+// `todo` = sample lanes that exist (lane < S) and are not blocked yet.
 template <bool COUNT>
 __device__ __forceinline__ unsigned long long sample_test(f3 d, f3 nd, float radius_sq, f3 c, float nA0, f3 p, f3 q,
-                                                          unsigned long long shadowed, Work& wk) {
+                                                          unsigned long long todo, Work& wk) {
   const float detA = detc(nd, c);
   float rr = rcp_newton(detA, 1);          // == 1.0f/detA, or NaN when detA is 0/denormal/inf (rt_math.h)
   float t = nA0 * rr;
@@ -115,7 +116,7 @@ __device__ __forceinline__ unsigned long long sample_test(f3 d, f3 nd, float rad
   // division fallback reaches the second stage, where it is recomputed exactly.
   unsigned long long pass = ballot(!(t < 0.0f)) & ballot(!(dist >= radius_sq));
   if (COUNT) wk.v[1] += 1;
-  if ((pass & ~shadowed) == 0ull) return 0ull;
+  if ((pass & todo) == 0ull) return 0ull;
   if (COUNT) wk.v[2] += 1;
   if (ballot(rr != rr) != 0ull) {                                    // rare: reciprocal outside v_rcp's range
     rr = 1.0f / detA;
@@ -132,7 +133,7 @@ __device__ __forceinline__ unsigned long long sample_test(f3 d, f3 nd, float rad
 // ---- brute force (CULL = false): every triangle for every surface point ---------------------------
 template <bool COUNT>
 __device__ __forceinline__ int wave_unshadowed_all(const FrameParams& P, const TriLane& T, const WaveLds& L, int lane,
-                                                   int ns, int j, f3 jit, Work& wk) {
+                                                   int ns, int j, f3 jit, unsigned long long active, Work& wk) {
   const float4 h0 = L.h0[j], h1 = L.h1[j];                 // LDS broadcasts
   const f3 start = mk(h0.x, h0.y, h0.z), dir = mk(h1.x, h1.y, h1.z);
   const float radius_sq = h0.w;
@@ -153,19 +154,19 @@ __device__ __forceinline__ int wave_unshadowed_all(const FrameParams& P, const T
     const float4 nxt = L.r0[i + 1 < 64 ? i + 1 : 63];     // prefetch the next record
     const float4 r1 = L.r1[i];
     const float2 r2 = L.r2[i];
-    shadowed |= sample_test<COUNT>(d, nd, radius_sq, mk(r0.x, r0.y, r0.z), r0.w, mk(r1.x, r1.y, r1.z),
-                                   mk(r1.w, r2.x, r2.y), shadowed, wk);
-    if (shadowed == ~0ull) break;                          // every sample blocked: any-hit early-out
+    shadowed |= active & sample_test<COUNT>(d, nd, radius_sq, mk(r0.x, r0.y, r0.z), r0.w, mk(r1.x, r1.y, r1.z),
+                                            mk(r1.w, r2.x, r2.y), active & ~shadowed, wk);
+    if (shadowed == active) break;                         // every sample blocked: any-hit early-out
     r0 = nxt;
   }
   __builtin_amdgcn_wave_barrier();
   bool sh = (shadowed >> lane) & 1ull;
-  if (P.nsph > 0 && shadowed != ~0ull) {
+  if (P.nsph > 0 && shadowed != active) {
     Work unused;
     if (COUNT) wk.v[3] += 1;
     if (!sh) sh = shadow_spheres<false>(P, start, d, radius_sq, unused);
   }
-  return __popcll(ballot(!sh));
+  return __popcll(active & ballot(!sh));
 }
 
 // ---- interval bounds ----------------------------------------------------------------------------------
@@ -282,7 +283,8 @@ __device__ __forceinline__ bool spheres_maybe(const FrameParams& P, f3 start, f3
 template <bool COUNT>
 __device__ __forceinline__ int wave_unshadowed_some(const FrameParams& P, const LdsScene& S, const int* sidx,
                                                     const WaveLds& L, int lane, int j, unsigned long long K,
-                                                    unsigned long long need, bool sph_maybe, f3 jit, Work& wk) {
+                                                    unsigned long long need, bool sph_maybe, f3 jit,
+                                                    unsigned long long active, Work& wk) {
   const float4 h0 = L.h0[j], h1 = L.h1[j];                 // LDS broadcasts
   const f3 start = mk(h0.x, h0.y, h0.z), dir = mk(h1.x, h1.y, h1.z);
   const float radius_sq = h0.w;
@@ -297,16 +299,16 @@ __device__ __forceinline__ int wave_unshadowed_some(const FrameParams& P, const 
     // sample-independent terms of (point j, triangle ti): wave-uniform inputs, same arithmetic as :251-270
     const f3 v0 = xyz(S.v0[ti]), e1 = xyz(S.e1[ti]), e2 = xyz(S.e2[ti]), c = xyz(S.c[ti]);
     const f3 b = start - v0;
-    shadowed |= sample_test<COUNT>(d, nd, radius_sq, c, detc(b, c), cof(b, e2), cof(e1, b), shadowed, wk);
-    if (shadowed == ~0ull) break;                          // every sample blocked: any-hit early-out
+    shadowed |= active & sample_test<COUNT>(d, nd, radius_sq, c, detc(b, c), cof(b, e2), cof(e1, b), active & ~shadowed, wk);
+    if (shadowed == active) break;                         // every sample blocked: any-hit early-out
   }
   bool sh = (shadowed >> lane) & 1ull;
-  if (sph_maybe && shadowed != ~0ull) {
+  if (sph_maybe && shadowed != active) {
     Work unused;
     if (COUNT) wk.v[3] += 1;
     if (!sh) sh = shadow_spheres<false>(P, start, d, radius_sq, unused);
   }
-  return __popcll(ballot(!sh));
+  return __popcll(active & ballot(!sh));
 }
 
 }  // namespace
@@ -361,6 +363,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void rt_draw_wave(const FrameP
   const f3 light = mk(P.light[0], P.light[1], P.light[2]);
   const float hbox = P.spread / 2.f;                                  // |crush()| <= range/2, :51
   const unsigned long long tri_lanes = ns == 64 ? ~0ull : ((1ull << ns) - 1ull);
+  const int NS = P.S;                                                 // shadow samples = sample lanes, <= 64
+  const unsigned long long active = NS == 64 ? ~0ull : ((1ull << NS) - 1ull);
 
   TriLane T;
   {
@@ -421,7 +425,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void rt_draw_wave(const FrameP
     __builtin_amdgcn_wave_barrier();
 
     // ---- phase 3: shadows of the lit surface points ---------------------------------------------------
-    int unshadowed = 64;                        // samples of this lane's surface point that reach the light
+    int unshadowed = NS;                        // samples of this lane's surface point that reach the light
     unsigned long long work = ballot(lit);      // lanes whose samples must really be tested (level 3)
     unsigned long long K = tri_lanes, need = ~0ull, sphmask = P.nsph > 0 ? ~0ull : 0ull;
     if (CULL && work != 0ull) {
@@ -488,7 +492,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void rt_draw_wave(const FrameP
         const uint32_t seed = comp == 0 ? (uint32_t)gid : (uint32_t)((float)gid * (comp == 1 ? 91.0f : 19.0f));
         uint32_t s = xorshift(seed);
         uint32_t* dst = L.rng + pp * kRngStride + comp;
-        for (int it = 0; it < 64; ++it) { s = xorshift(s); dst[it * 4] = s; }
+        for (int it = 0; it < NS; ++it) { s = xorshift(s); dst[it * 4] = s; }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -508,9 +512,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void rt_draw_wave(const FrameP
           if (CULL) {
             const unsigned long long nj = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(need >> 32), j) << 32) |
                                           (unsigned)__builtin_amdgcn_readlane((int)need, j);
-            cnt = wave_unshadowed_some<COUNT>(P, S, sidx, L, lane, j, K, nj, (sphmask >> j) & 1ull, jit, xw);
+            cnt = wave_unshadowed_some<COUNT>(P, S, sidx, L, lane, j, K, nj, (sphmask >> j) & 1ull, jit, active, xw);
           } else {
-            cnt = wave_unshadowed_all<COUNT>(P, T, L, lane, ns, j, jit, xw);
+            cnt = wave_unshadowed_all<COUNT>(P, T, L, lane, ns, j, jit, active, xw);
           }
           if (lane == j) unshadowed = cnt;
         }
@@ -525,9 +529,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void rt_draw_wave(const FrameP
     f3 contrib = mk(0.f, 0.f, 0.f);
     if (lit) {
       float total = 0.0f;
-      if (unshadowed < 64) total += 0.0f * term;          // a blocked sample adds 0*term (NaN/inf-faithful)
-      for (int i = 0; i < 64; ++i) if (i < unshadowed) total += term;
-      const float l = 0.5f + total / 64.0f;
+      if (unshadowed < NS) total += 0.0f * term;          // a blocked sample adds 0*term (NaN/inf-faithful)
+      for (int i = 0; i < NS; ++i) if (i < unshadowed) total += term;
+      const float l = 0.5f + total / (float)NS;
       if (secondary) { const float kk = 0.9f * l; contrib = mk(kk * ray.col.x, kk * ray.col.y, kk * ray.col.z); }
       else contrib = mk(ray.col.x * l, ray.col.y * l, ray.col.z * l);
     }
@@ -575,7 +579,7 @@ template __global__ void rt_draw_wave<true, false, true>(const FrameParams);
 
 bool wave_kernel_supports(const FrameParams& P) {
   const int aa = P.aa_x * P.aa_y;
-  return P.S == 64 && aa >= 1 && aa <= 64 && (64 % aa) == 0 && P.n >= 1 && P.n <= 64 && P.n_shadow >= 1 &&
+  return P.S >= 1 && P.S <= 64 && aa >= 1 && aa <= 64 && (64 % aa) == 0 && P.n >= 1 && P.n <= 64 && P.n_shadow >= 1 &&
          P.spread >= 0.0f;
 }
 
