@@ -1,0 +1,46 @@
+"""-m gpu: Loader.cpp-style OBJ meshes added to the Cornell Box (skeleton.cpp:102-103) — triangle counts
+beyond the 64-triangle wave kernel and beyond one LDS stage (512), against the CPU oracle, bit for bit."""
+import numpy as np
+import pytest
+
+from conftest import focal_for
+from uob_raytracer_amd import abi, meshgen, runtime as rt
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n_lon,n_lat,kw", [
+    (10, 8, dict(width=96, height=64, aa_x=1, aa_y=1, shadow_samples=2)),              # 166 triangles: LDS stage
+    (10, 8, dict(width=64, height=48, aa_x=2, aa_y=2, shadow_samples=3, spheres=())),
+    (40, 30, dict(width=96, height=64, aa_x=1, aa_y=1, shadow_samples=1, light_spread=0.0)),   # 2346: HBM records
+    (40, 30, dict(width=48, height=32, aa_x=2, aa_y=1, shadow_samples=2)),
+])
+def test_box_plus_mesh_vs_oracle(n_lon, n_lat, kw, scene, oracle, tmp_path):
+    path = str(tmp_path / "mesh.obj")
+    nf = meshgen.write_sphere_obj(path, n_lon, n_lat)
+    both = scene + rt.Scene.load_obj(path)
+    assert len(both) == 26 + nf
+    cfg = abi.make_config(**kw)
+    v, n, c = both.packed()
+    tr = rt.RayTracer(cfg, both)
+    for yaw, pitch, cam, light in [(0.0, 0.0, [0.0, 0.0, -3.2], [0.0, -0.5, -0.7]), (0.3, 0.1, [0.3, 0.2, -2.6], [0.2, -0.6, -0.4])]:
+        rot = rt.rotation_matrix(yaw, pitch)
+        argb, rgb = tr.render(rot, cam, light, focal_for(cfg), want_rgb=True)
+        o_argb, o_rgb = oracle.render(cfg, v, n, c, rot, cam, light, focal_for(cfg))
+        assert np.array_equal(argb.ravel(), o_argb)
+        assert np.array_equal(rgb[..., :3].reshape(-1, 3).view(np.uint32), o_rgb.view(np.uint32))
+        assert (argb != 0xFF000000).mean() > 0.5
+    work = tr.count_work(rot, cam, light, focal_for(cfg))
+    assert work["closest_tri_tests"] == (26 + nf) * (work["primary_rays"] + work["bounce_rays"])
+    tr.close()
+
+
+def test_mesh_casts_a_shadow_and_is_visible(scene, tmp_path):
+    """Sanity of the placement: the mesh changes the frame (it is inside the view, on the floor)."""
+    path = str(tmp_path / "mesh.obj")
+    meshgen.write_sphere_obj(path, 16, 12)
+    cfg = abi.make_config(width=128, height=128, aa_x=1, aa_y=1, shadow_samples=4)
+    rot, cam, light = rt.rotation_matrix(0, 0), [0.0, 0.0, -3.2], [0.0, -0.5, -0.7]
+    a0 = rt.RayTracer(cfg, scene).render(rot, cam, light, focal_for(cfg))
+    a1 = rt.RayTracer(cfg, scene + rt.Scene.load_obj(path)).render(rot, cam, light, focal_for(cfg))
+    assert 0.01 < (a0 != a1).mean() < 0.5

@@ -32,6 +32,7 @@ void set_error(const char* fmt, ...) {
 }
 
 void launch_generic(const FrameParams& P, bool count, hipStream_t stream);
+bool generic_needs_records(int n);
 void launch_wave(const FrameParams& P, bool cull, bool count, hipStream_t stream);
 void launch_wave_prof(const FrameParams& P, hipStream_t stream);
 bool wave_kernel_supports(const FrameParams& P);
@@ -58,6 +59,7 @@ struct rt_ctx {
   uint32_t* d_argb = nullptr;      // internal framebuffer for rt_render
   float4* d_rgb = nullptr;         // lazily allocated float tap
   unsigned long long* d_counters = nullptr;
+  float4* d_records = nullptr;     // staged records in HBM for meshes beyond one LDS stage
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
@@ -132,10 +134,7 @@ int rt_init(const rt_config* cfg, const float* vertices4, const float* normals4,
     }
   }
   if (cfg->flags & RT_FLAG_FAST_MATH) { set_error("RT_FLAG_FAST_MATH is not built into this library"); return RT_E_UNSUPPORTED; }
-  if ((size_t)n * 8 * sizeof(float4) > 64 * 1024) {
-    set_error("triangle list of %d does not fit one LDS stage (max %d); tiled staging is not available yet", n, (int)(64 * 1024 / 128));
-    return RT_E_UNSUPPORTED;
-  }
+  if (n > 4000000) { set_error("triangle list of %d exceeds the supported maximum of 4000000", n); return RT_E_UNSUPPORTED; }
   int ndev = 0;
   HIP_TRY(hipGetDeviceCount(&ndev));
   if (ndev < 1) { set_error("no HIP device present"); return RT_E_DEVICE; }
@@ -152,6 +151,9 @@ int rt_init(const rt_config* cfg, const float* vertices4, const float* normals4,
   if (hipMalloc(&c->d_verts, 3 * nb) != hipSuccess || hipMalloc(&c->d_normals, nb) != hipSuccess ||
       hipMalloc(&c->d_colors, nb) != hipSuccess || hipMalloc(&c->d_argb, px * 4) != hipSuccess ||
       hipMalloc(&c->d_counters, sizeof(rt_work)) != hipSuccess) {
+    set_error("hipMalloc failed: %s", hipGetErrorString(hipGetLastError())); return fail(RT_E_NOMEM);
+  }
+  if (generic_needs_records(n) && hipMalloc(&c->d_records, (size_t)n * 8 * sizeof(float4)) != hipSuccess) {
     set_error("hipMalloc failed: %s", hipGetErrorString(hipGetLastError())); return fail(RT_E_NOMEM);
   }
   if (hipStreamCreate(&c->stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
@@ -192,6 +194,7 @@ static void fill_params(const rt_ctx* c, const float rot[12], const float cam[3]
     memcpy(P->sph[i].col, g.spheres[i].color, 16);
   }
   P->verts = c->d_verts; P->normals = c->d_normals; P->colors = c->d_colors;
+  P->records = c->d_records;
 }
 
 static int launch_frame(rt_ctx* c, const float rot[12], const float cam[3], const float light[3], float focal,
@@ -291,7 +294,7 @@ void rt_destroy(rt_ctx* c) {
   if (c->ev0) hipEventDestroy(c->ev0);
   if (c->ev1) hipEventDestroy(c->ev1);
   hipFree(c->d_verts); hipFree(c->d_normals); hipFree(c->d_colors);
-  hipFree(c->d_argb); hipFree(c->d_rgb); hipFree(c->d_counters);
+  hipFree(c->d_argb); hipFree(c->d_rgb); hipFree(c->d_counters); hipFree(c->d_records);
   delete c;
 }
 

@@ -35,6 +35,7 @@ struct FrameParams {
   uint32_t* out_argb;     // owned_rows * W ARGB8888 words
   float4* out_rgb;        // nullable: owned_rows * W pre-quantisation colours
   unsigned long long* counters;  // nullable: rt_work, 8 x u64
+  float4* records;        // staged triangle records in HBM (8 x n float4), used when n exceeds one LDS stage
 };
 
 // Map a packed local row index to the global image row (band partition, include/uob_rt.h rt_config).

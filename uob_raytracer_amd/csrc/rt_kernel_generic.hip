@@ -43,13 +43,23 @@ __device__ float direct_light(const LdsScene& S, const FrameParams& P, const Ray
 
 }  // namespace
 
+// Stage the records of a mesh that does not fit one LDS stage into HBM instead (P.records), once per frame.
+__global__ __launch_bounds__(256) void rt_stage_records(const FrameParams P) {
+  stage_triangles(P, P.records, (long)blockIdx.x * 256 + threadIdx.x, (long)gridDim.x * 256);
+}
+
 // kernels.cl:368-428.  Grid: x = ceil(W/64), y = ceil(owned_rows/4); block 64x4.
-template <bool COUNT>
+// BIG = the triangle records are read from HBM/L2 (every lane the same address) instead of LDS: the path
+// for meshes of more than kLdsMaxTriangles triangles until the LDS-tiled traversal exists.
+template <bool COUNT, bool BIG>
 __global__ __launch_bounds__(256) void rt_draw_generic(const FrameParams P) {
-  extern __shared__ float4 lds[];
+  extern __shared__ float4 lds_dyn[];
   const int tid = threadIdx.y * 64 + threadIdx.x;
-  stage_triangles(P, lds, tid, 256);
-  __syncthreads();
+  const float4* lds = BIG ? P.records : lds_dyn;
+  if (!BIG) {
+    stage_triangles(P, lds_dyn, tid, 256);
+    __syncthreads();
+  }
 
   const int x = blockIdx.x * 64 + threadIdx.x;
   const int lr = blockIdx.y * 4 + threadIdx.y;
@@ -98,15 +108,25 @@ __global__ __launch_bounds__(256) void rt_draw_generic(const FrameParams P) {
   }
 }
 
-template __global__ void rt_draw_generic<false>(const FrameParams);
-template __global__ void rt_draw_generic<true>(const FrameParams);
+template __global__ void rt_draw_generic<false, false>(const FrameParams);
+template __global__ void rt_draw_generic<true, false>(const FrameParams);
+template __global__ void rt_draw_generic<false, true>(const FrameParams);
+template __global__ void rt_draw_generic<true, true>(const FrameParams);
+
+bool generic_needs_records(int n) { return n > kLdsMaxTriangles; }
 
 void launch_generic(const FrameParams& P, bool count, hipStream_t stream) {
   const dim3 block(64, 4);
   const dim3 grid((P.W + 63) / 64, (P.owned_rows + 3) / 4);
+  if (generic_needs_records(P.n)) {
+    hipLaunchKernelGGL(rt_stage_records, dim3((P.n + 255) / 256), dim3(256), 0, stream, P);
+    if (count) hipLaunchKernelGGL((rt_draw_generic<true, true>), grid, block, 0, stream, P);
+    else hipLaunchKernelGGL((rt_draw_generic<false, true>), grid, block, 0, stream, P);
+    return;
+  }
   const size_t lds_bytes = (size_t)P.n * kLdsRecords * sizeof(float4);
-  if (count) hipLaunchKernelGGL(rt_draw_generic<true>, grid, block, lds_bytes, stream, P);
-  else hipLaunchKernelGGL(rt_draw_generic<false>, grid, block, lds_bytes, stream, P);
+  if (count) hipLaunchKernelGGL((rt_draw_generic<true, false>), grid, block, lds_bytes, stream, P);
+  else hipLaunchKernelGGL((rt_draw_generic<false, false>), grid, block, lds_bytes, stream, P);
 }
 
 }  // namespace uobrt

@@ -22,10 +22,13 @@ __device__ __forceinline__ LdsScene lds_scene(const float4* lds, int n) {
   return LdsScene{lds, lds + n, lds + 2 * n, lds + 3 * n, lds + 4 * n, lds + 5 * n, lds + 6 * n, lds + 7 * n, n};
 }
 
-__device__ __forceinline__ void stage_triangles(const FrameParams& P, float4* lds, int tid, int nthreads) {
+// Triangles that fit one LDS stage (8 records of 16 B each, 64 KB)
+constexpr int kLdsMaxTriangles = 512;
+
+__device__ __forceinline__ void stage_triangles(const FrameParams& P, float4* lds, long tid, long nthreads) {
   const int n = P.n;
   const f3 cam = mk(P.cam[0], P.cam[1], P.cam[2]);
-  for (int i = tid; i < n; i += nthreads) {
+  for (long i = tid; i < n; i += nthreads) {
     const float4 a = P.verts[3 * i], b = P.verts[3 * i + 1], c = P.verts[3 * i + 2];
     const f3 v0 = xyz(a), e1 = xyz(b) - v0, e2 = xyz(c) - v0;
     const f3 cf = cof(e1, e2);

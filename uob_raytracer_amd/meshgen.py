@@ -1,0 +1,35 @@
+"""Synthetic Wavefront OBJ meshes in the only syntax the reference's loader accepts (`v x y z`, `f a b c`,
+Loader.cpp:39-46).  The reference's call site loads "Source/bunny_200.obj" (skeleton.cpp:102), a file that
+is not in the reference repository, so tests and benchmarks write their own meshes with this module."""
+import math
+
+
+def write_sphere_obj(path, n_lon=32, n_lat=24, radius=0.13, center=(0.0, 0.25, 0.0), bumps=0.15):
+    """A bumpy UV sphere of 2*n_lon*(n_lat-1) triangles.  In OBJ space; load_obj scales by 1.5, negates and
+    translates by (-0.4, 1.15, -0.7) (Loader.cpp:42,48-52), which puts this default on the floor of the box."""
+    verts = []
+    for j in range(n_lat + 1):
+        th = math.pi * j / n_lat
+        for i in range(n_lon):
+            ph = 2.0 * math.pi * i / n_lon
+            r = radius * (1.0 + bumps * math.sin(5 * ph) * math.sin(4 * th))
+            verts.append((center[0] + r * math.sin(th) * math.cos(ph), center[1] + r * math.cos(th),
+                          center[2] + r * math.sin(th) * math.sin(ph)))
+    faces = []
+    for j in range(n_lat):
+        for i in range(n_lon):
+            a = j * n_lon + i
+            b = j * n_lon + (i + 1) % n_lon
+            c = a + n_lon
+            d = b + n_lon
+            if j > 0:
+                faces.append((a + 1, c + 1, b + 1))
+            if j < n_lat - 1:
+                faces.append((b + 1, c + 1, d + 1))
+    with open(path, "w") as f:
+        f.write("# synthetic bumpy sphere: %d vertices, %d faces\n" % (len(verts), len(faces)))
+        for v in verts:
+            f.write("v %.7f %.7f %.7f\n" % v)
+        for t in faces:
+            f.write("f %d %d %d\n" % t)
+    return len(faces)
