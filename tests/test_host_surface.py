@@ -1,0 +1,78 @@
+"""The C++ host mirror of the reference's application surface (uob_raytracer_amd/csrc/host/):
+screen / InitializeSDL / PutPixelSDL / SDL_SaveImage (SDLauxiliary.h) on the CPU, and the whole
+main-loop binary (skeleton.cpp main/update/offload_rendering) on the GPU."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+HOST = os.path.join(ROOT, "uob_raytracer_amd", "csrc", "host")
+
+
+def read_bmp(path):
+    raw = open(path, "rb").read()
+    assert raw[:2] == b"BM"
+    off, = struct.unpack_from("<I", raw, 10)
+    hsize, w, h, planes, bpp, comp = struct.unpack_from("<IiiHHI", raw, 14)
+    assert (hsize, planes, bpp, comp) == (108, 1, 32, 3) and h > 0          # V4 header, BI_BITFIELDS, bottom-up
+    assert struct.unpack_from("<IIII", raw, 54) == (0x00FF0000, 0x0000FF00, 0x000000FF, 0xFF000000)
+    px = np.frombuffer(raw, np.uint32, w * h, off).reshape(h, w)
+    return px[::-1].copy()
+
+
+def test_putpixel_and_saveimage(tmp_path):
+    src = tmp_path / "t.cpp"
+    src.write_text('#include "screen.h"\nint main(int c,char**v){screen*s=InitializeSDL(5,3,false);'
+                   'PutPixelSDL(s,0,0,1.0f,0.5f,0.0f);PutPixelSDL(s,4,2,2.0f,-1.0f,0.999f);PutPixelSDL(s,9,9,0,0,0);'
+                   'SDL_Renderframe(s);SDL_SaveImage(s,v[1]);int r=(int)s->frames_presented;KillSDL(s);return r==1?0:1;}\n')
+    exe = tmp_path / "t"
+    subprocess.run(["g++", "-std=c++11", "-I", HOST, str(src), os.path.join(HOST, "screen.cpp"), "-o", str(exe)], check=True)
+    out = tmp_path / "o.bmp"
+    subprocess.run([str(exe), str(out)], check=True, stdout=subprocess.DEVNULL)
+    px = read_bmp(str(out))
+    assert px.shape == (3, 5)
+    assert px[0, 0] == (128 << 24) + (255 << 16) + (127 << 8) + 0          # SDLauxiliary.h:157-161, alpha 128
+    assert px[2, 4] == (128 << 24) + (255 << 16) + (0 << 8) + 254          # clamp, truncation
+    assert px[1, 1] == 0
+
+
+@pytest.mark.gpu
+def test_main_loop_binary_matches_python_path(tmp_path, scene):
+    from uob_raytracer_amd import abi, runtime as rt
+    exe = os.path.join(ROOT, "uob_raytracer_amd", "uob_raytracer")
+    out = str(tmp_path / "shot.bmp")
+    keys = ["left", "i", "k", "up"]
+    res = subprocess.run([exe, "--size", "128", "--frames", "6", "--keys", " ".join(keys), "--out", out],
+                         check=True, capture_output=True, text=True)
+    assert "Triangles Length size 26" in res.stdout and res.stdout.count("Frame Rate:") == 6
+    # replay update() (skeleton.cpp:282-361) in float32 / double exactly as the C++ does
+    f32, f64 = np.float32, np.float64
+    lx, lor, yaw, pitch, cx, cz = f32(0.0), True, f32(0.0), f32(0.0), f32(0.0), f32(-3.2)
+    for k in range(6):
+        if lor:
+            diff = f32(-0.5) - lx
+            if diff > f32(-0.001):
+                lor = False
+            lx = lx + diff / f32(20.0)
+        else:
+            diff = f32(0.5) - lx
+            if diff < f32(0.001):
+                lor = True
+            lx = lx + diff / f32(20.0)
+        if k < len(keys):
+            key = keys[k]
+            if key == "left": yaw = f32(f64(yaw) + 0.1)
+            if key == "up": pitch = f32(f64(pitch) - 0.1)
+            if key == "i": cz = f32(f64(cz) + 0.1)
+            if key == "k": cx = f32(f64(cx) + 0.1)
+    cfg = abi.make_config(width=128, height=128)
+    tr = rt.RayTracer(cfg, scene)
+    want = tr.render(rt.rotation_matrix(float(yaw), float(pitch)), [cx, 0.0, cz], [lx, -0.5, -0.7], 1100.0 * 128 / 1024 * 2)
+    tr.close()
+    got = read_bmp(out)
+    assert np.array_equal(got, want)
+    assert ("light_position.x %.9g" % lx) in res.stdout
