@@ -279,36 +279,73 @@ __device__ __forceinline__ bool spheres_maybe(const FrameParams& P, f3 start, f3
   return maybe;
 }
 
-// Level 3 (lane = sample): surface point j against the triangles of K whose bit is set in `need`.
+// Level 3 (lane = sample): TWO surface points ja, jb of one pixel (same jitter) per pass against the
+// triangles of K whose bit is set in `need` (the union of the two points' sets: testing a triangle a point
+// does not need cannot produce a hit for it, that is what the bound proved).  Two points per pass give the
+// dependent chain  LDS record -> determinants -> reciprocal -> compares  two independent instances to
+// interleave: with one point per pass this level ran at ~20 % VALU utilisation, bound by latency (7.8 ms
+// of the headline frame; 5.5 ms with two; four or eight points cost more in registers than they gain).
+// SC = the shadow-casting triangles' records (v0,e1,e2,c) in K's bit order.  Returns both counts.
+struct ShadowCasters { const float4 *v0, *e1, *e2, *c; };
+struct Count2 { int a, b; };
 template <bool COUNT>
-__device__ __forceinline__ int wave_unshadowed_some(const FrameParams& P, const LdsScene& S, const int* sidx,
-                                                    const WaveLds& L, int lane, int j, unsigned long long K,
-                                                    unsigned long long need, bool sph_maybe, f3 jit,
-                                                    unsigned long long active, Work& wk) {
-  const float4 h0 = L.h0[j], h1 = L.h1[j];                 // LDS broadcasts
-  const f3 start = mk(h0.x, h0.y, h0.z), dir = mk(h1.x, h1.y, h1.z);
-  const float radius_sq = h0.w;
-  const f3 d = dir + jit;       // shadow_ray.direction + crush(rand_vec, light_spread), :333
-  const f3 nd = -d;
-  if (COUNT) wk.v[0] += 1;
-  unsigned long long shadowed = 0ull;
+__device__ __forceinline__ Count2 wave_unshadowed_pair(const FrameParams& P, const ShadowCasters& SC, const WaveLds& L,
+                                                       int lane, int ja, int jb, unsigned long long K,
+                                                       unsigned long long need, bool sph_a, bool sph_b, f3 jit,
+                                                       unsigned long long active, Work& wk) {
+  const float4 ha0 = L.h0[ja], ha1 = L.h1[ja], hb0 = L.h0[jb], hb1 = L.h1[jb];     // LDS broadcasts
+  const f3 sa = mk(ha0.x, ha0.y, ha0.z), sb = mk(hb0.x, hb0.y, hb0.z);
+  const float ra = ha0.w, rb = hb0.w;
+  const f3 da = mk(ha1.x, ha1.y, ha1.z) + jit, db = mk(hb1.x, hb1.y, hb1.z) + jit;   // dir + crush(...), :333
+  const f3 nda = -da, ndb = -db;
+  if (COUNT) wk.v[0] += (ja == jb) ? 1 : 2;
+  unsigned long long sha = 0ull, shb = 0ull;
   int pos = 0;
   for (unsigned long long kk = K; kk != 0ull; kk &= kk - 1ull, ++pos) {
     if (((need >> pos) & 1ull) == 0ull) continue;
-    const int ti = sidx[__builtin_ctzll(kk)];
-    // sample-independent terms of (point j, triangle ti): wave-uniform inputs, same arithmetic as :251-270
-    const f3 v0 = xyz(S.v0[ti]), e1 = xyz(S.e1[ti]), e2 = xyz(S.e2[ti]), c = xyz(S.c[ti]);
-    const f3 b = start - v0;
-    shadowed |= active & sample_test<COUNT>(d, nd, radius_sq, c, detc(b, c), cof(b, e2), cof(e1, b), active & ~shadowed, wk);
-    if (shadowed == active) break;                         // every sample blocked: any-hit early-out
+    const int k = __builtin_ctzll(kk);
+    const f3 v0 = xyz(SC.v0[k]), e1 = xyz(SC.e1[k]), e2 = xyz(SC.e2[k]), c = xyz(SC.c[k]);
+    // first stage for both points, :251-266 (negated compares: also true for NaN, see rcp_newton)
+    const f3 ba = sa - v0, bb = sb - v0;
+    const float nA0a = detc(ba, c), nA0b = detc(bb, c);
+    const float detAa = detc(nda, c), detAb = detc(ndb, c);
+    float rra = rcp_newton(detAa, 1), rrb = rcp_newton(detAb, 1);
+    float ta = nA0a * rra, tb = nA0b * rrb;
+    f3 dva = ta * da, dvb = tb * db;
+    float dista = dva.x * dva.x + dva.y * dva.y + dva.z * dva.z;
+    float distb = dvb.x * dvb.x + dvb.y * dvb.y + dvb.z * dvb.z;
+    unsigned long long passa = ballot(!(ta < 0.0f)) & ballot(!(dista >= ra));
+    unsigned long long passb = ballot(!(tb < 0.0f)) & ballot(!(distb >= rb));
+    if (COUNT) wk.v[1] += (ja == jb) ? 1 : 2;
+    if (((passa & active & ~sha) | (passb & active & ~shb)) == 0ull) continue;
+    if (COUNT) wk.v[2] += 1;
+    if ((ballot(rra != rra) | ballot(rrb != rrb)) != 0ull) {         // rare: reciprocal outside v_rcp's range
+      rra = 1.0f / detAa; rrb = 1.0f / detAb;
+      ta = nA0a * rra; tb = nA0b * rrb;
+      dva = ta * da; dvb = tb * db;
+      dista = dva.x * dva.x + dva.y * dva.y + dva.z * dva.z;
+      distb = dvb.x * dvb.x + dvb.y * dvb.y + dvb.z * dvb.z;
+      passa = ballot(ta >= 0) & ballot(dista < ra);
+      passb = ballot(tb >= 0) & ballot(distb < rb);
+    }
+    // second stage, :268-272
+    const float ua = detc(nda, cof(ba, e2)) * rra, va = detc(nda, cof(e1, ba)) * rra;
+    const float ub = detc(ndb, cof(bb, e2)) * rrb, vb = detc(ndb, cof(e1, bb)) * rrb;
+    sha |= active & passa & ballot(ua >= 0) & ballot(va >= 0) & ballot((ua + va) <= 1);
+    shb |= active & passb & ballot(ub >= 0) & ballot(vb >= 0) & ballot((ub + vb) <= 1);
+    if (sha == active && shb == active) break;             // every sample of both points blocked
   }
-  bool sh = (shadowed >> lane) & 1ull;
-  if (sph_maybe && shadowed != active) {
+  bool sh_a = (sha >> lane) & 1ull, sh_b = (shb >> lane) & 1ull;
+  if ((sph_a && sha != active) || (sph_b && shb != active)) {
     Work unused;
     if (COUNT) wk.v[3] += 1;
-    if (!sh) sh = shadow_spheres<false>(P, start, d, radius_sq, unused);
+    if (sph_a && !sh_a) sh_a = shadow_spheres<false>(P, sa, da, ra, unused);
+    if (sph_b && !sh_b) sh_b = shadow_spheres<false>(P, sb, db, rb, unused);
   }
-  return __popcll(active & ballot(!sh));
+  Count2 r;
+  r.a = __popcll(active & ballot(!sh_a));
+  r.b = __popcll(active & ballot(!sh_b));
+  return r;
 }
 
 }  // namespace
@@ -348,7 +385,16 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void rt_draw_wave(const FrameP
   }
   RT_STAMP(7)                               // 7: staging work before the workgroup barrier
   __syncthreads();
-  const WaveLds L = wave_lds(reinterpret_cast<char*>(sidx + ((n + 3) & ~3)) + wave * wave_lds_bytes(CULL), CULL);
+  // the shadow-casting triangles' (v0,e1,e2,c) once more, in caster order: levels 2 and 3 index them by
+  // the bit position of the candidate mask, with no index indirection in their dependent chains
+  float4* scbase = reinterpret_cast<float4*>(sidx + ((n + 3) & ~3));
+  for (int kq = tid; kq < ns; kq += 64 * kWavesPerBlock) {
+    const int ti = sidx[kq];
+    scbase[kq] = lds[ti]; scbase[ns + kq] = lds[n + ti]; scbase[2 * ns + kq] = lds[2 * n + ti]; scbase[3 * ns + kq] = lds[3 * n + ti];
+  }
+  __syncthreads();
+  const ShadowCasters SC{scbase, scbase + ns, scbase + 2 * ns, scbase + 3 * ns};
+  const WaveLds L = wave_lds(reinterpret_cast<char*>(scbase + 4 * ns) + wave * wave_lds_bytes(CULL), CULL);
 
   const int lr = blockIdx.y * kWavesPerBlock + wave;
   if (lr >= P.owned_rows) return;                                     // whole wave; no block barrier follows
@@ -466,9 +512,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void rt_draw_wave(const FrameP
         need = 0ull;
         int pos = 0;
         for (unsigned long long kk = K; kk != 0ull; kk &= kk - 1ull, ++pos) {
-          const int ti = sidx[__builtin_ctzll(kk)];
-          const Bound pb = point_bound(start, dir, hh, dlen, dminlen, dk, xyz(S.v0[ti]), xyz(S.e1[ti]), xyz(S.e2[ti]),
-                                       xyz(S.c[ti]));
+          const int kq = __builtin_ctzll(kk);
+          const Bound pb = point_bound(start, dir, hh, dlen, dminlen, dk, xyz(SC.v0[kq]), xyz(SC.e1[kq]), xyz(SC.e2[kq]),
+                                       xyz(SC.c[kq]));
           if (!pb.clear || !sane) need |= 1ull << pos;
           blocked = blocked || (sane && pb.all_blocked);
         }
@@ -508,15 +554,21 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void rt_draw_wave(const FrameP
         while (pm != 0ull) {
           const int j = base + __builtin_ctzll(pm);
           pm &= pm - 1ull;
-          int cnt;
           if (CULL) {
-            const unsigned long long nj = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(need >> 32), j) << 32) |
+            const int j2 = pm != 0ull ? base + __builtin_ctzll(pm) : j;   // second point of the pair (or j again)
+            pm &= pm - 1ull;                                             // 0 & anything stays 0
+            const unsigned long long n1 = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(need >> 32), j) << 32) |
                                           (unsigned)__builtin_amdgcn_readlane((int)need, j);
-            cnt = wave_unshadowed_some<COUNT>(P, S, sidx, L, lane, j, K, nj, (sphmask >> j) & 1ull, jit, active, xw);
+            const unsigned long long n2 = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(need >> 32), j2) << 32) |
+                                          (unsigned)__builtin_amdgcn_readlane((int)need, j2);
+            const Count2 c2 = wave_unshadowed_pair<COUNT>(P, SC, L, lane, j, j2, K, n1 | n2, (sphmask >> j) & 1ull,
+                                                          (sphmask >> j2) & 1ull, jit, active, xw);
+            if (lane == j2) unshadowed = c2.b;
+            if (lane == j) unshadowed = c2.a;
           } else {
-            cnt = wave_unshadowed_all<COUNT>(P, T, L, lane, ns, j, jit, active, xw);
+            const int cnt = wave_unshadowed_all<COUNT>(P, T, L, lane, ns, j, jit, active, xw);
+            if (lane == j) unshadowed = cnt;
           }
-          if (lane == j) unshadowed = cnt;
         }
       }
       __builtin_amdgcn_wave_barrier();          // scratch is rewritten by the next group
@@ -585,7 +637,7 @@ bool wave_kernel_supports(const FrameParams& P) {
 
 static size_t wave_kernel_lds(const FrameParams& P, bool cull) {
   return (size_t)P.n * kLdsRecords * sizeof(float4) + (size_t)((P.n + 3) & ~3) * sizeof(int) +
-         kWavesPerBlock * (size_t)wave_lds_bytes(cull);
+         (size_t)P.n_shadow * 4 * sizeof(float4) + kWavesPerBlock * (size_t)wave_lds_bytes(cull);
 }
 
 void launch_wave_prof(const FrameParams& P, hipStream_t stream) {
