@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--cpu-sample-pixels", type=int, default=0, help="0 = auto (about 10-30 s of CPU work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-brute-force", action="store_true", help="skip the cull-off comparison leg (N=1 only)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = rehearsal of the N>1 flow on a box with fewer GPUs than ranks (bands travel via host memory)")
     args = ap.parse_args()
 
     import torch
@@ -63,11 +65,16 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
         args.gpus = world
+    if args.backend == "gloo":          # rehearsal: several ranks may share one GPU
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend="gloo")
 
     wl = WORKLOADS[args.workload]
     W, H = wl["width"], wl["height"]
@@ -95,12 +102,25 @@ def main():
         if ev:
             ev[1].record()
         # N > 1: one RCCL gather of the finished bands + de-interleave on rank 0; N == 1: the stripe IS the frame
-        bands.gather_frame(stripe, world, rank, band_rows, gathered, frame)
+        if args.backend == "gloo" and world > 1:
+            host = bands.gather_frame(stripe.cpu(), world, rank, band_rows)
+            if rank == 0:
+                frame.copy_(host)
+        else:
+            bands.gather_frame(stripe, world, rank, band_rows, gathered, frame)
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def reduce_(t, op):
+        if args.backend == "gloo":
+            c = t.cpu()
+            dist.all_reduce(c, op=op)
+            t.copy_(c)
+        else:
+            dist.all_reduce(t, op=op)
 
     # exact algorithmic work of this rank's bands (un-timed instrumented passes): `work` follows the
     # reference's loops literally (rt_count_work); `executed` is what the wave kernel really runs
@@ -126,9 +146,9 @@ def main():
                          dtype=torch.float64, device=dev)
     if world > 1:
         mx = stats[:2].clone()
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        reduce_(mx, dist.ReduceOp.MAX)
         sm = stats[2:].clone()
-        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        reduce_(sm, dist.ReduceOp.SUM)
         stats = torch.cat([mx, sm])
     stats = stats.cpu().numpy()
     elapsed, kernel_ms = float(stats[0]), float(stats[1])
