@@ -367,7 +367,12 @@ constexpr int kWavesPerBlock = RT_WAVES_PER_BLOCK;
     tlast = now_;                                                                   \
   }
 template <bool CULL, bool COUNT, bool PROF = false>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void rt_draw_wave(const FrameParams P) {
+// 5 waves per SIMD (<= 96 VGPRs, 36 B/lane of scratch spills): the kernel is bound by instruction issue
+// latency at low occupancy, 5 waves measured 11.3 ms vs 12.4 ms unconstrained (4 waves) and 11.5 ms at 6
+#ifndef RT_MIN_WAVES
+#define RT_MIN_WAVES 5
+#endif
+__global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wave(const FrameParams P) {
   unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tlast = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
   extern __shared__ float4 lds[];
@@ -412,12 +417,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void rt_draw_wave(const FrameP
   const int NS = P.S;                                                 // shadow samples = sample lanes, <= 64
   const unsigned long long active = NS == 64 ? ~0ull : ((1ull << NS) - 1ull);
 
+  // triangle lane i < ns holds shadow-casting triangle i: resident in registers in the brute-force build,
+  // re-read from LDS once per task by level 1 in the culled build (registers are what limits occupancy)
+  const int tl = lane < ns ? lane : 0;
   TriLane T;
-  {
-    const int ti = sidx[lane < ns ? lane : 0];
-    T.v0 = xyz(S.v0[ti]); T.e1 = xyz(S.e1[ti]); T.e2 = xyz(S.e2[ti]); T.c = xyz(S.c[ti]);
+  if (!CULL) {
+    T.v0 = xyz(SC.v0[tl]); T.e1 = xyz(SC.e1[tl]); T.e2 = xyz(SC.e2[tl]); T.c = xyz(SC.c[tl]);
     T.c1 = norm1(T.c); T.e1_1 = norm1(T.e1); T.e2_1 = norm1(T.e2);
-    if (!CULL) L.r0[lane] = make_float4(T.c.x, T.c.y, T.c.z, 0.f);   // static part of record 0
+    L.r0[lane] = make_float4(T.c.x, T.c.y, T.c.z, 0.f);   // static part of record 0
   }
 
   RT_STAMP(0)                               // 0: staging + set-up
@@ -497,7 +504,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void rt_draw_wave(const FrameP
         const bool all_sane = ballot(lit && !sane) == 0ull;
         if (all_sane && es < 1e30f && ed < 1e30f) {                    // finite, non-degenerate
           const float hh_task = 1.002f * hbox + 2e-6f * (dlen_max + hbox);
-          const Bound tb = task_bound(T, s0, D0, es, ed, hh_task, dlen_min, dlen_max);
+          TriLane T1;
+          T1.v0 = xyz(SC.v0[tl]); T1.e1 = xyz(SC.e1[tl]); T1.e2 = xyz(SC.e2[tl]); T1.c = xyz(SC.c[tl]);
+          T1.c1 = norm1(T1.c); T1.e1_1 = norm1(T1.e1); T1.e2_1 = norm1(T1.e2);
+          const Bound tb = task_bound(T1, s0, D0, es, ed, hh_task, dlen_min, dlen_max);
           K = tri_lanes & ~ballot(tb.clear);
           task_blocked = (tri_lanes & ballot(tb.all_blocked)) != 0ull;
         }
@@ -579,13 +589,21 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void rt_draw_wave(const FrameP
     if (P.debug_stop == 4) { outc = outc + mk((float)unshadowed, term, ray.col.x); continue; }
     // ---- phase 4: shade lane-parallel (direct_light's sum :335, then :354 / :421-422) ----------------
     f3 contrib = mk(0.f, 0.f, 0.f);
-    if (lit) {
+    {
+      // direct_light's running sum (:335): the same term added once per unblocked sample, in sequence.
+      // Most tasks have every lit lane fully lit: then the adds need no per-lane predicate.
       float total = 0.0f;
-      if (unshadowed < NS) total += 0.0f * term;          // a blocked sample adds 0*term (NaN/inf-faithful)
-      for (int i = 0; i < NS; ++i) if (i < unshadowed) total += term;
-      const float l = 0.5f + total / (float)NS;
-      if (secondary) { const float kk = 0.9f * l; contrib = mk(kk * ray.col.x, kk * ray.col.y, kk * ray.col.z); }
-      else contrib = mk(ray.col.x * l, ray.col.y * l, ray.col.z * l);
+      if (ballot(lit && unshadowed != NS) == 0ull) {
+        for (int i = 0; i < NS; ++i) total += term;
+      } else {
+        if (unshadowed < NS) total += 0.0f * term;        // a blocked sample adds 0*term (NaN/inf-faithful)
+        for (int i = 0; i < NS; ++i) if (i < unshadowed) total += term;
+      }
+      if (lit) {
+        const float l = 0.5f + total / (float)NS;
+        if (secondary) { const float kk = 0.9f * l; contrib = mk(kk * ray.col.x, kk * ray.col.y, kk * ray.col.z); }
+        else contrib = mk(ray.col.x * l, ray.col.y * l, ray.col.z * l);
+      }
     }
     // sum the AA rays of each pixel in index order (final_color_total +=, :415-425); a ray without a
     // contribution adds +0, which leaves the running sum unchanged bit for bit
