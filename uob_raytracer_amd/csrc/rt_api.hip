@@ -59,6 +59,7 @@ struct rt_ctx {
   uint32_t* d_argb = nullptr;      // internal framebuffer for rt_render
   float4* d_rgb = nullptr;         // lazily allocated float tap
   unsigned long long* d_counters = nullptr;
+  unsigned int* d_jobctr = nullptr; // wave kernel's job counter
   float4* d_records = nullptr;     // staged records in HBM for meshes beyond one LDS stage
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -150,7 +151,7 @@ int rt_init(const rt_config* cfg, const float* vertices4, const float* normals4,
   const size_t px = (size_t)(c->owned_rows > 0 ? c->owned_rows : 1) * cfg->width;
   if (hipMalloc(&c->d_verts, 3 * nb) != hipSuccess || hipMalloc(&c->d_normals, nb) != hipSuccess ||
       hipMalloc(&c->d_colors, nb) != hipSuccess || hipMalloc(&c->d_argb, px * 4) != hipSuccess ||
-      hipMalloc(&c->d_counters, sizeof(rt_work)) != hipSuccess) {
+      hipMalloc(&c->d_counters, sizeof(rt_work)) != hipSuccess || hipMalloc(&c->d_jobctr, 64) != hipSuccess) {
     set_error("hipMalloc failed: %s", hipGetErrorString(hipGetLastError())); return fail(RT_E_NOMEM);
   }
   if (generic_needs_records(n) && hipMalloc(&c->d_records, (size_t)n * 8 * sizeof(float4)) != hipSuccess) {
@@ -195,6 +196,9 @@ static void fill_params(const rt_ctx* c, const float rot[12], const float cam[3]
   }
   P->verts = c->d_verts; P->normals = c->d_normals; P->colors = c->d_colors;
   P->records = c->d_records;
+  P->job_counter = c->d_jobctr;
+  P->nseg = (g.width + 63) / 64;
+  P->njobs = P->nseg * c->owned_rows;
 }
 
 static int launch_frame(rt_ctx* c, const float rot[12], const float cam[3], const float light[3], float focal,
@@ -294,7 +298,7 @@ void rt_destroy(rt_ctx* c) {
   if (c->ev0) hipEventDestroy(c->ev0);
   if (c->ev1) hipEventDestroy(c->ev1);
   hipFree(c->d_verts); hipFree(c->d_normals); hipFree(c->d_colors);
-  hipFree(c->d_argb); hipFree(c->d_rgb); hipFree(c->d_counters); hipFree(c->d_records);
+  hipFree(c->d_argb); hipFree(c->d_rgb); hipFree(c->d_counters); hipFree(c->d_records); hipFree(c->d_jobctr);
   delete c;
 }
 

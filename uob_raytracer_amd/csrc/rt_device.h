@@ -35,6 +35,8 @@ struct FrameParams {
   uint32_t* out_argb;     // owned_rows * W ARGB8888 words
   float4* out_rgb;        // nullable: owned_rows * W pre-quantisation colours
   unsigned long long* counters;  // nullable: rt_work, 8 x u64
+  unsigned int* job_counter;   // wave kernel: next 64-pixel segment to hand out (zeroed before each launch)
+  int32_t njobs, nseg;    // segments in total / per row
   float4* records;        // staged triangle records in HBM (8 x n float4), used when n exceeds one LDS stage
 };
 
