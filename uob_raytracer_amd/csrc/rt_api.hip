@@ -188,7 +188,6 @@ static void fill_params(const rt_ctx* c, const float rot[12], const float cam[3]
   P->owned_rows = c->owned_rows;
   P->sy = (float)g.aa_x / (float)g.aa_y;
   P->n_shadow = c->n_shadow;
-  { const char* e = getenv("UOB_RT_DEBUG_STOP"); P->debug_stop = e ? atoi(e) : 0; }
   for (int i = 0; i < g.num_spheres; ++i) {
     P->sph[i].cx = g.spheres[i].center[0]; P->sph[i].cy = g.spheres[i].center[1]; P->sph[i].cz = g.spheres[i].center[2];
     P->sph[i].r2 = g.spheres[i].radius_sq;

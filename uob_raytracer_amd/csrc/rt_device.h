@@ -27,7 +27,6 @@ struct FrameParams {
   int32_t band_rows, band_index, band_count, owned_rows;
   float sy;               // aa_x / aa_y: y sub-pixel pitch in x sub-pixel units (1 for square grids)
   int32_t n_shadow;       // triangles that can cast a shadow (glass removed), for the wave kernel
-  int32_t debug_stop;     // diagnostics: 1 = return right after staging, 2 = after primary rays
   DevSphere sph[RT_MAX_SPHERES];
   const float4* verts;    // float4[3n]  (HBM, read once per workgroup while staging into LDS)
   const float4* normals;  // float4[n]

@@ -45,6 +45,14 @@ __device__ __forceinline__ float rl(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 __device__ __forceinline__ float shfl(float v, int lane) { return __shfl(v, lane, 64); }
+// A copy of the lane id the optimiser cannot see through.  Addresses and constants derived from it are
+// recomputed where they are used (2-3 cheap VALU instructions) instead of being hoisted out of the task loop
+// and kept in registers for the whole kernel — hoisted LDS addresses were what pushed the kernel past 96
+// VGPRs and into scratch spills, each reload a ~500-cycle dependent VMEM access inside the hot loops.
+__device__ __forceinline__ int opaque(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
 __device__ __forceinline__ unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ float norm1(f3 a) { return fabsf(a.x) + fabsf(a.y) + fabsf(a.z); }
 // Wave-wide reductions.  The result is the same in every lane; readfirstlane tells the compiler so
@@ -440,9 +448,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
   const int y = band_global_row(lr, P.band_rows, P.band_index, P.band_count);
   f3 outc = mk(0.f, 0.f, 0.f);
   for (int k = 0; k < aa; ++k) {
-    // ---- phase 1: 64 primary rays, lane = (pixel, AA sample) -----------------------------------------
-    const int pj = k * PT + (lane >> la);       // pixel of this lane within the 64-pixel job
-    const int a = lane & (aa - 1);              // AA sample index dy*rx+dx, kernels.cl:395
+    const int lnA = opaque(lane);
+    // ---- phase 1: 64 primary rays, lnA = (pixel, AA sample) -----------------------------------------
+    const int pj = k * PT + (lnA >> la);       // pixel of this lnA within the 64-pixel job
+    const int a = lnA & (aa - 1);              // AA sample index dy*rx+dx, kernels.cl:395
     const int x = x0 + pj;
     const bool valid = x < P.W;
     Ray ray = primary_ray(P, x, y, a % P.aa_x, a / P.aa_x);
@@ -459,7 +468,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
       const f3 eu = mk(1.0001f * (fabsf(r0.x) * hx + fabsf(r0.y) * hy), 1.0001f * (fabsf(r1.x) * hx + fabsf(r1.y) * hy),
                        1.0001f * (fabsf(r2.x) * hx + fabsf(r2.y) * hy));
       const float dumax = fmaxf(fmaxf(fabsf(duc.x) + eu.x, fabsf(duc.y) + eu.y), fabsf(duc.z) + eu.z);
-      const int ti = lane < n ? lane : 0;
+      const int ti = lnA < n ? lnA : 0;
       const float4 c4 = S.c[ti];
       const bool clear = primary_clear(duc, eu, dumax, xyz(c4), c4.w, xyz(S.pc[ti]), xyz(S.qc[ti]));
       if (dumax < 1e30f) Kp &= ~ballot(clear);
@@ -473,20 +482,20 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
         else lit = true;
       }
     }
-    if (P.debug_stop == 2) { outc = outc + ray.P + mk(lit ? 1.f : 0.f, ray.N.x, ray.col.x); continue; }
     RT_STAMP(1)                             // 1: primary rays + bounces
-    // per-lane light set-up of direct_light, :323-326
+    const int lnB = opaque(lane);
+    // per-lnB light set-up of direct_light, :323-326
     const f3 dir = light - ray.P;
     const f3 start = ray.P + 0.0001f * dir;
     const float radius_sq = dir.x * dir.x + dir.y * dir.y + dir.z * dir.z;
     const float term = (16.0f * fmaxf(dot3(dir, ray.N), 0.0f)) / (4.0f * 3.14159274f * radius_sq);
     __builtin_amdgcn_wave_barrier();
-    L.h0[lane] = make_float4(start.x, start.y, start.z, radius_sq);
-    L.h1[lane] = make_float4(dir.x, dir.y, dir.z, 0.f);
+    L.h0[lnB] = make_float4(start.x, start.y, start.z, radius_sq);
+    L.h1[lnB] = make_float4(dir.x, dir.y, dir.z, 0.f);
     __builtin_amdgcn_wave_barrier();
 
     // ---- phase 3: shadows of the lit surface points ---------------------------------------------------
-    int unshadowed = NS;                        // samples of this lane's surface point that reach the light
+    int unshadowed = NS;                        // samples of this lnB's surface point that reach the light
     unsigned long long work = ballot(lit);      // lanes whose samples must really be tested (level 3)
     unsigned long long K = tri_lanes, need = ~0ull, sphmask = P.nsph > 0 ? ~0ull : 0ull;
     if (CULL && work != 0ull) {
@@ -498,7 +507,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
       if (!sane || !(dminlen > 0.0f)) dminlen = 0.0f;                  // disables the distance rule
       const float dk = dlen * 1.000004f;
       sphmask = ballot(lit && P.nsph > 0 && spheres_maybe(P, start, dir, dlen, hh));
-      // level 1: all lit points of the task at once, lane = triangle
+      // level 1: all lit points of the task at once, lnB = triangle
       bool task_blocked = false;
       {
         const int jr = __builtin_ctzll(work);
@@ -513,7 +522,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
         if (all_sane && es < 1e30f && ed < 1e30f) {                    // finite, non-degenerate
           const float hh_task = 1.002f * hbox + 2e-6f * (dlen_max + hbox);
           TriLane T1;
-          T1.v0 = xyz(SC.v0[tl]); T1.e1 = xyz(SC.e1[tl]); T1.e2 = xyz(SC.e2[tl]); T1.c = xyz(SC.c[tl]);
+          T1.v0 = xyz(SC.v0[(lnB < ns ? lnB : 0)]); T1.e1 = xyz(SC.e1[(lnB < ns ? lnB : 0)]); T1.e2 = xyz(SC.e2[(lnB < ns ? lnB : 0)]); T1.c = xyz(SC.c[(lnB < ns ? lnB : 0)]);
           T1.c1 = norm1(T1.c); T1.e1_1 = norm1(T1.e1); T1.e2_1 = norm1(T1.e2);
           const Bound tb = task_bound(T1, s0, D0, es, ed, hh_task, dlen_min, dlen_max);
           K = tri_lanes & ~ballot(tb.clear);
@@ -525,7 +534,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
         unshadowed = 0; work = 0ull;
         if (COUNT) xw.v[5] += 1;
       } else {
-        // level 2: per surface point, lane = point, over the triangles K that survived level 1
+        // level 2: per surface point, lnB = point, over the triangles K that survived level 1
         bool blocked = false;
         need = 0ull;
         int pos = 0;
@@ -537,21 +546,21 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
           blocked = blocked || (sane && pb.all_blocked);
         }
         if (blocked) unshadowed = 0;
-        work = ballot(lit && !blocked && (need != 0ull || ((sphmask >> lane) & 1ull) != 0ull));
+        work = ballot(lit && !blocked && (need != 0ull || ((sphmask >> lnB) & 1ull) != 0ull));
         if (COUNT) { xw.v[4] += (unsigned)__popcll(ballot(lit && !blocked && need == 0ull)); if (work == 0ull) xw.v[5] += 1; }
       }
     }
 
-    if (P.debug_stop == 3) { outc = outc + mk((float)unshadowed, (float)__popcll(work), (float)(need & 0xffff) + term); continue; }
     RT_STAMP(3)                             // 3: level 2
+    const int lnC = opaque(lane);
     // level 3 / brute force: the reference's sample test, one surface point at a time
     const int GL = GP * aa;                     // lanes per RNG group
     for (int g = 0; g * GL < 64 && work != 0ull; ++g) {
       const unsigned long long gm = (work >> (g * GL)) & (GL == 64 ? ~0ull : ((1ull << GL) - 1ull));
       if (gm == 0ull) continue;
-      // xorshift streams of the GP pixels of this group: lane c -> (pixel c/3, component c%3), :319,:331
-      if (lane < 3 * GP && P.debug_stop != 5) {
-        const int pp = lane / 3, comp = lane % 3;
+      // xorshift streams of the GP pixels of this group: lnC c -> (pixel c/3, component c%3), :319,:331
+      if (lnC < 3 * GP) {
+        const int pp = lnC / 3, comp = lnC % 3;
         const int gid = pixel_global_id(P, x0 + k * PT + g * GP + pp, y);
         const uint32_t seed = comp == 0 ? (uint32_t)gid : (uint32_t)((float)gid * (comp == 1 ? 91.0f : 19.0f));
         uint32_t s = xorshift(seed);
@@ -565,10 +574,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
       for (int pp = 0; pp < GP; ++pp) {
         unsigned long long pm = (gm >> (pp * aa)) & (aa == 64 ? ~0ull : ((1ull << aa) - 1ull));
         if (pm == 0ull) continue;
-        const uint32_t* src = L.rng + pp * kRngStride + lane * 4;     // lane = sample index
+        const uint32_t* src = L.rng + pp * kRngStride + lnC * 4;     // lnC = sample index
         const f3 jit = mk(crush1(src[0], P.spread), crush1(src[1], P.spread), crush1(src[2], P.spread));
         const int base = g * GL + pp * aa;
-        if (P.debug_stop == 6) { outc = outc + jit; continue; }
         while (pm != 0ull) {
           const int j = base + __builtin_ctzll(pm);
           pm &= pm - 1ull;
@@ -579,13 +587,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
                                           (unsigned)__builtin_amdgcn_readlane((int)need, j);
             const unsigned long long n2 = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(need >> 32), j2) << 32) |
                                           (unsigned)__builtin_amdgcn_readlane((int)need, j2);
-            const Count2 c2 = wave_unshadowed_pair<COUNT>(P, SC, L, lane, j, j2, K, n1 | n2, (sphmask >> j) & 1ull,
+            const Count2 c2 = wave_unshadowed_pair<COUNT>(P, SC, L, lnC, j, j2, K, n1 | n2, (sphmask >> j) & 1ull,
                                                           (sphmask >> j2) & 1ull, jit, active, xw);
-            if (lane == j2) unshadowed = c2.b;
-            if (lane == j) unshadowed = c2.a;
+            if (lnC == j2) unshadowed = c2.b;
+            if (lnC == j) unshadowed = c2.a;
           } else {
-            const int cnt = wave_unshadowed_all<COUNT>(P, T, L, lane, ns, j, jit, active, xw);
-            if (lane == j) unshadowed = cnt;
+            const int cnt = wave_unshadowed_all<COUNT>(P, T, L, lnC, ns, j, jit, active, xw);
+            if (lnC == j) unshadowed = cnt;
           }
         }
       }
@@ -594,12 +602,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
     }
     RT_STAMP(5)
 
-    if (P.debug_stop == 4) { outc = outc + mk((float)unshadowed, term, ray.col.x); continue; }
-    // ---- phase 4: shade lane-parallel (direct_light's sum :335, then :354 / :421-422) ----------------
+    const int lnD = opaque(lane);
+    // ---- phase 4: shade lnD-parallel (direct_light's sum :335, then :354 / :421-422) ----------------
     f3 contrib = mk(0.f, 0.f, 0.f);
     {
       // direct_light's running sum (:335): the same term added once per unblocked sample, in sequence.
-      // Most tasks have every lit lane fully lit: then the adds need no per-lane predicate.
+      // Most tasks have every lit lnD fully lit: then the adds need no per-lnD predicate.
       float total = 0.0f;
       if (ballot(lit && unshadowed != NS) == 0ull) {
         for (int i = 0; i < NS; ++i) total += term;
@@ -616,13 +624,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
     // sum the AA rays of each pixel in index order (final_color_total +=, :415-425); a ray without a
     // contribution adds +0, which leaves the running sum unchanged bit for bit
     f3 acc = mk(0.f, 0.f, 0.f);
-    const int first = (lane >> la) << la;
+    const int first = (lnD >> la) << la;
     for (int r = 0; r < aa; ++r) {
       acc = acc + mk(shfl(contrib.x, first + r), shfl(contrib.y, first + r), shfl(contrib.z, first + r));
     }
-    // pixel pj's sum lives in lanes [pj*aa, pj*aa+aa); hand it to output lane (k*PT + pj)
+    // pixel pj's sum lives in lanes [pj*aa, pj*aa+aa); hand it to output lnD (k*PT + pj)
     {
-      const int rel = lane - k * PT;
+      const int rel = lnD - k * PT;
       const int srcl = (rel >= 0 && rel < PT) ? (rel << la) : 0;
       const f3 v = mk(shfl(acc.x, srcl), shfl(acc.y, srcl), shfl(acc.z, srcl));
       if (rel >= 0 && rel < PT) outc = v;
