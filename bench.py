@@ -186,18 +186,16 @@ def main():
                         "interval bound instead of 64 per-sample tests, so the algorithmic rate can exceed the "
                         "hardware peak; `executed` is the arithmetic really issued."}
     if total_exec:
-        ns = len(scene)   # shadow-casting triangles (no glass in the shipped scene)
-        ex_flop = 64 * (total_exec["stage1_wave_iterations"] * 19 + total_exec["stage2_wave_iterations"] * 13) + \
-            total_exec["surface_points"] * ns * 64 + \
-            (total_work["closest_tri_tests"] * 27 + total_work["closest_sphere_tests"] * 30)
-        ex_tflops = ex_flop / world / (kernel_ms * 1e-3) / 1e12
         roofline["executed"] = {
             "sample_triangle_tests": 64 * total_exec["stage1_wave_iterations"],
             "fraction_of_reference_tests": 64 * total_exec["stage1_wave_iterations"] / max(total_work["shadow_tri_tests"], 1),
-            "culled_pairs": total_exec["culled_pairs"], "surface_points": total_exec["surface_points"],
-            "tflops": ex_tflops, "frac": ex_tflops / PEAK_FP32_VALU_TFLOPS,
-            "note": "flop issued by the kernel: 19 per first-stage sample test, 13 per second-stage, 64 per "
-                    "(surface point, triangle) set-up+bound, 27/30 per primary/bounce closest-hit test"}
+            "surface_points_sampled": total_exec["surface_points"],
+            "surface_points_decided_lit_by_bounds": total_exec["culled_pairs"],
+            "tasks_decided_whole": total_exec["tasks_resolved_whole"],
+            "lit_surface_points": total_work["lit_hits"],
+            "note": "work the shipped kernel really executes (rt_count_executed): the 64-sample test runs only for "
+                    "(surface point, triangle) pairs the interval bounds leave undecided; PMC instruction counts "
+                    "are in profiles/"}
 
     out = {
         "metric": "Mrays/sec (nominal = W*H*AA*(1+S)/t), Cornell Box 4096^2, 8xAA, 64 shadow rays",

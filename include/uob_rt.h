@@ -107,11 +107,12 @@ int rt_render_device(rt_ctx* ctx, const float rot[12], const float cam[3], const
 int rt_count_work(rt_ctx* ctx, const float rot[12], const float cam[3], const float light[3],
                   float focal, rt_work* out);
 
-/* Work the 64-sample wave kernel actually EXECUTES for the frame (un-timed instrumented pass; fails with
- * RT_E_UNSUPPORTED for configurations that run on the generic kernel).  out[0] = surface points lit,
- * out[1] = first-stage (t) wave iterations = 64 sample tests each, out[2] = second-stage (u,v) wave
- * iterations, out[3] = wave-wide sphere evaluations, out[4] = (surface point, triangle) pairs removed by
- * the per-point interval cull, out[5] = 64-ray tasks resolved whole by the task-level bound, out[6..7] = 0.                                                                    */
+/* Work the wave kernel actually EXECUTES for the frame (un-timed instrumented pass; fails with
+ * RT_E_UNSUPPORTED for configurations that run on the generic kernel).  out[0] = surface points whose
+ * samples were tested (level 3), out[1] = first-stage (t) sample-test passes = 64 sample tests each,
+ * out[2] = second-stage (u,v) passes, out[3] = wave-wide sphere evaluations, out[4] = lit surface points
+ * decided fully lit by the interval bounds, out[5] = 64-ray tasks that needed no sampling at all,
+ * out[6..7] = 0.                                                                                        */
 int rt_count_executed(rt_ctx* ctx, const float rot[12], const float cam[3], const float light[3],
                       float focal, uint64_t out[8]);
 
