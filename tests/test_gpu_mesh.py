@@ -14,13 +14,16 @@ pytestmark = pytest.mark.gpu
     (10, 8, dict(width=64, height=48, aa_x=2, aa_y=2, shadow_samples=3, spheres=())),
     (40, 30, dict(width=96, height=64, aa_x=1, aa_y=1, shadow_samples=1, light_spread=0.0)),   # 2346: HBM records
     (40, 30, dict(width=48, height=32, aa_x=2, aa_y=1, shadow_samples=2)),
+    (24, 16, dict(width=80, height=60, aa_x=2, aa_y=2, shadow_samples=64, light_spread=0.3)),     # wide penumbrae
+    (12, 9, dict(width=70, height=41, aa_x=4, aa_y=2, shadow_samples=10, spheres=())),            # ragged frame
 ])
-def test_box_plus_mesh_vs_oracle(n_lon, n_lat, kw, scene, oracle, tmp_path):
+@pytest.mark.parametrize("flags", [0, abi.RT_FLAG_GENERIC_KERNEL])     # tiled wave kernel / thread-per-pixel kernel
+def test_box_plus_mesh_vs_oracle(n_lon, n_lat, kw, flags, scene, oracle, tmp_path):
     path = str(tmp_path / "mesh.obj")
     nf = meshgen.write_sphere_obj(path, n_lon, n_lat)
     both = scene + rt.Scene.load_obj(path)
     assert len(both) == 26 + nf
-    cfg = abi.make_config(**kw)
+    cfg = abi.make_config(flags=flags, **kw)
     v, n, c = both.packed()
     tr = rt.RayTracer(cfg, both)
     for yaw, pitch, cam, light in [(0.0, 0.0, [0.0, 0.0, -3.2], [0.0, -0.5, -0.7]), (0.3, 0.1, [0.3, 0.2, -2.6], [0.2, -0.6, -0.4])]:

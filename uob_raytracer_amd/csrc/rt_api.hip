@@ -33,6 +33,9 @@ void set_error(const char* fmt, ...) {
 
 void launch_generic(const FrameParams& P, bool count, hipStream_t stream);
 bool generic_needs_records(int n);
+void launch_stage_records(const FrameParams& P, hipStream_t stream);
+void launch_mesh(const FrameParams& P, hipStream_t stream);
+bool mesh_kernel_supports(const FrameParams& P);
 void launch_wave(const FrameParams& P, bool cull, bool count, hipStream_t stream);
 void launch_wave_prof(const FrameParams& P, hipStream_t stream);
 bool wave_kernel_supports(const FrameParams& P);
@@ -154,7 +157,7 @@ int rt_init(const rt_config* cfg, const float* vertices4, const float* normals4,
       hipMalloc(&c->d_counters, sizeof(rt_work)) != hipSuccess || hipMalloc(&c->d_jobctr, 64) != hipSuccess) {
     set_error("hipMalloc failed: %s", hipGetErrorString(hipGetLastError())); return fail(RT_E_NOMEM);
   }
-  if (generic_needs_records(n) && hipMalloc(&c->d_records, (size_t)n * 8 * sizeof(float4)) != hipSuccess) {
+  if (n > 64 && hipMalloc(&c->d_records, (size_t)n * 8 * sizeof(float4)) != hipSuccess) {
     set_error("hipMalloc failed: %s", hipGetErrorString(hipGetLastError())); return fail(RT_E_NOMEM);
   }
   if (hipStreamCreate(&c->stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
@@ -213,8 +216,15 @@ static int launch_frame(rt_ctx* c, const float rot[12], const float cam[3], cons
   P.out_argb = d_argb; P.out_rgb = d_rgb; P.counters = nullptr;
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipEventRecord(c->ev0, stream));
-  if (!(c->cfg.flags & RT_FLAG_GENERIC_KERNEL) && wave_kernel_supports(P)) launch_wave(P, !(c->cfg.flags & RT_FLAG_NO_CULL), false, stream);
-  else launch_generic(P, false, stream);
+  const bool wave_paths = !(c->cfg.flags & RT_FLAG_GENERIC_KERNEL);
+  if (wave_paths && wave_kernel_supports(P)) {
+    launch_wave(P, !(c->cfg.flags & RT_FLAG_NO_CULL), false, stream);
+  } else if (wave_paths && !(c->cfg.flags & RT_FLAG_NO_CULL) && mesh_kernel_supports(P)) {
+    launch_stage_records(P, stream);        // per frame: the records hold camera-dependent terms
+    launch_mesh(P, stream);
+  } else {
+    launch_generic(P, false, stream);
+  }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(c->ev1, stream));
   c->timed = true;

@@ -115,11 +115,15 @@ template __global__ void rt_draw_generic<true, true>(const FrameParams);
 
 bool generic_needs_records(int n) { return n > kLdsMaxTriangles; }
 
+void launch_stage_records(const FrameParams& P, hipStream_t stream) {
+  hipLaunchKernelGGL(rt_stage_records, dim3((P.n + 255) / 256), dim3(256), 0, stream, P);
+}
+
 void launch_generic(const FrameParams& P, bool count, hipStream_t stream) {
   const dim3 block(64, 4);
   const dim3 grid((P.W + 63) / 64, (P.owned_rows + 3) / 4);
   if (generic_needs_records(P.n)) {
-    hipLaunchKernelGGL(rt_stage_records, dim3((P.n + 255) / 256), dim3(256), 0, stream, P);
+    launch_stage_records(P, stream);
     if (count) hipLaunchKernelGGL((rt_draw_generic<true, true>), grid, block, 0, stream, P);
     else hipLaunchKernelGGL((rt_draw_generic<false, true>), grid, block, 0, stream, P);
     return;

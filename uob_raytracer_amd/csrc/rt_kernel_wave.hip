@@ -32,49 +32,11 @@
 //
 // Arithmetic is the reference's, operation for operation (rt_math.h): results are bit-identical to the
 // generic kernel and to the CPU oracle.
-#include "rt_trace.h"
+#include "rt_wave_common.h"
 
 namespace uobrt {
 
 namespace {
-
-constexpr int kRngPixels = 4;               // pixels whose sample streams are generated together
-constexpr int kRngStride = 64 * 4 + 4;      // 32-bit words per pixel in the scratch (+4: bank spread)
-
-__device__ __forceinline__ float rl(float v, int lane) {
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
-}
-__device__ __forceinline__ float shfl(float v, int lane) { return __shfl(v, lane, 64); }
-// A copy of the lane id the optimiser cannot see through.  Addresses and constants derived from it are
-// recomputed where they are used (2-3 cheap VALU instructions) instead of being hoisted out of the task loop
-// and kept in registers for the whole kernel — hoisted LDS addresses were what pushed the kernel past 96
-// VGPRs and into scratch spills, each reload a ~500-cycle dependent VMEM access inside the hot loops.
-__device__ __forceinline__ int opaque(int v) {
-  asm volatile("" : "+v"(v));
-  return v;
-}
-__device__ __forceinline__ unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
-__device__ __forceinline__ float norm1(f3 a) { return fabsf(a.x) + fabsf(a.y) + fabsf(a.z); }
-// Wave-wide reductions.  The result is the same in every lane; readfirstlane tells the compiler so
-// (otherwise everything derived from it — the candidate masks, the loops over them — is treated as
-// divergent and kept in VGPRs with exec-mask loops).
-__device__ __forceinline__ float uniform(float v) {
-  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
-}
-__device__ __forceinline__ float wave_max(float v) {
-  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-  return uniform(v);
-}
-__device__ __forceinline__ float wave_min(float v) {
-  for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
-  return uniform(v);
-}
-
-// Per-lane registers of a "triangle lane" (lane i < ns holds shadow-casting triangle i)
-struct TriLane {
-  f3 v0, e1, e2, c;
-  float c1, e1_1, e2_1;    // 1-norms |c|, |e1|, |e2| (interval bounds)
-};
 
 // Per-wave LDS.
 //   r0..r2 (brute-force path): sample-independent terms of (surface point, triangle i), written by
@@ -175,116 +137,6 @@ __device__ __forceinline__ int wave_unshadowed_all(const FrameParams& P, const T
     if (!sh) sh = shadow_spheres<false>(P, start, d, radius_sq, unused);
   }
   return __popcll(active & ballot(!sh));
-}
-
-// ---- interval bounds ----------------------------------------------------------------------------------
-// Level 1 (lane = triangle): can ANY shadow sample of ANY lit surface point of the current task hit this
-// triangle (`clear` = no), and do ALL of them hit it (`all_blocked`)?
-//   s0, D0 : start / dir of a reference surface point;  es, ed : max |component| deviation of the other
-//            points' start / dir from it;  hh : jitter half-width incl. rounding slack (max over points);
-//   dlen_min/max : range of |dir| over the points.
-struct Bound { bool clear, all_blocked; };
-__device__ __forceinline__ Bound task_bound(const TriLane& T, f3 s0, f3 D0, float es, float ed, float hh,
-                                            float dlen_min, float dlen_max) {
-  const f3 b0 = s0 - T.v0;
-  const float binf = fmaxf(fmaxf(fabsf(b0.x), fabsf(b0.y)), fabsf(b0.z));
-  const float eb = 1.001f * es + 1e-6f * (binf + es);              // |b - b0| per component, any point
-  const float nA0 = detc(b0, T.c);
-  const f3 p0 = cof(b0, T.e2), q0 = cof(T.e1, b0);
-  const float p1 = norm1(p0), q1 = norm1(q0);
-  const float ep1 = 2.002f * eb * T.e2_1, eq1 = 2.002f * eb * T.e1_1;   // sum_k |p_k - p0_k|, |q_k - q0_k|
-  const f3 md = -D0;
-  const float A0 = detc(md, T.c), N1 = detc(md, p0), N2 = detc(md, q0);
-  const float edd = 1.001f * ed + hh;                               // |d - D0| per component, any point, any sample
-  const float E0 = eb * T.c1 * 1.0001f;
-  const float EA = edd * T.c1 * 1.0001f;
-  const float E1 = (dlen_max * ep1 + edd * (p1 + ep1)) * 1.0001f;
-  const float E2 = (dlen_max * eq1 + edd * (q1 + eq1)) * 1.0001f;
-  const float aD = fabsf(A0), hiD = aD + EA, loD = aD - EA;
-  const bool robust = aD > EA + 1e-30f;
-  const float sg = copysignf(1.0f, A0);
-  const float tn = sg * nA0, un = sg * N1, vn = sg * N2;
-  const float dmin = fmaxf(dlen_min - 1.7321f * hh, 0.0f), dmax = dlen_max + 1.7321f * hh;
-  // A sample can only hit if det(A), det(A0), det(A1), det(A2) share one sign (t,u,v >= 0): cull when
-  // neither the all-positive nor the all-negative combination is possible.  No condition on det(A): this
-  // also settles rays that are nearly parallel to the triangle's plane, where det(A) changes sign.
-  const bool can_pos = (A0 + EA > 0.0f) && (nA0 + E0 > -1e-18f) && (N1 + E1 > -1e-18f) && (N2 + E2 > -1e-18f);
-  const bool can_neg = (A0 - EA < 0.0f) && (nA0 - E0 < 1e-18f) && (N1 - E1 < 1e-18f) && (N2 - E2 < 1e-18f);
-  const bool cR = (fabsf(nA0) - E0) * dmin > hiD * (dlen_max * 1.000004f);   // |t d|^2 >= radius_sq everywhere
-  const bool cW = fabsf(N1 + N2) - (E1 + E2) > hiD * 1.000004f;              // u+v > 1 wherever u,v >= 0
-  Bound r;
-  r.clear = (!can_pos && !can_neg) || cR || cW;
-  r.all_blocked = robust && (tn - E0 > 1e-18f) && (un - E1 > 1e-18f) && (vn - E2 > 1e-18f) &&
-                  ((un + vn) + (E1 + E2) < loD * 0.999996f) &&
-                  ((fabsf(nA0) + E0) * dmax < loD * (dlen_min * 0.999996f));
-  return r;
-}
-
-// Level 2 (lane = surface point): the same question for ONE point (this lane's) and a wave-uniform
-// triangle.  hh >= h plus every rounding error of the per-sample evaluation; every sample's det(A) lies in
-// D0 +- hh*|c|_1, det(A1) in N1 +- hh*|p|_1, det(A2) in N2 +- hh*|q|_1 (they are linear in the direction).
-__device__ __forceinline__ Bound point_bound(f3 start, f3 dir, float hh, float dlen, float dminlen, float dk,
-                                             f3 v0, f3 e1, f3 e2, f3 c) {
-  const f3 b = start - v0;
-  const f3 p = cof(b, e2), q = cof(e1, b);
-  const float nA0 = detc(b, c);
-  const f3 md = -dir;
-  const float D0 = detc(md, c), N1 = detc(md, p), N2 = detc(md, q);
-  const float aD = fabsf(D0);
-  const float Delta = hh * norm1(c);
-  const bool robust = aD > Delta + 1e-30f;           // every sample's det(A) has D0's sign and is normal
-  const float sg = copysignf(1.0f, D0);
-  const float tn = sg * nA0, un = sg * N1, vn = sg * N2;
-  const float hp = hh * norm1(p), hq = hh * norm1(q);
-  const float hiD = aD + Delta, loD = aD - Delta;
-  // sign consistency of det(A), det(A0), det(A1), det(A2) (see task_bound); det(A0) is exact here
-  const bool can_pos = (D0 + Delta > 0.0f) && (nA0 > -1e-18f) && (N1 + hp > -1e-18f) && (N2 + hq > -1e-18f);
-  const bool can_neg = (D0 - Delta < 0.0f) && (nA0 < 1e-18f) && (N1 - hp < 1e-18f) && (N2 - hq < 1e-18f);
-  const bool cR = fabsf(nA0) * dminlen > hiD * dk;               // |t*d|^2 >= radius_sq for every sample
-  const bool cW = fabsf(N1 + N2) - (hp + hq) > hiD * 1.000004f;  // u+v > 1 wherever u,v >= 0
-  Bound r;
-  r.clear = (!can_pos && !can_neg) || cR || cW;
-  r.all_blocked = robust && (tn > 1e-18f) && (un - hp > 1e-18f) && (vn - hq > 1e-18f) &&
-                  ((un + vn) + (hp + hq) < loD * 0.999996f) &&
-                  (fabsf(nA0) * (dlen + 1.7321f * hh) < loD * (dlen * 0.999996f));
-  return r;
-}
-
-// Primary rays of one task (lane = triangle i < n): can ANY of the task's rays hit this triangle?
-// The rays leave the camera through the sub-pixel rectangle [wc +- (hx,hy)] x {focal}; before
-// normalisation their directions are du = R w, i.e. duc +- eu per component, and every determinant of
-// the test is linear in the direction, so the sign/ratio conditions can be checked on du (they are
-// invariant under the positive scale 1/|du|).  slack covers the roundings of R w, of the normalisation
-// and of the per-ray determinant evaluation (each a few 2^-24 relative to |du|_max * |cofactors|_1).
-__device__ __forceinline__ bool primary_clear(f3 duc, f3 eu, float dumax, f3 c, float nA0cam, f3 pc, f3 qc) {
-  const f3 md = -duc;
-  const float Ac = detc(md, c), N1 = detc(md, pc), N2 = detc(md, qc);
-  const float sl = 4e-6f * dumax;
-  const float EA = eu.x * fabsf(c.x) + eu.y * fabsf(c.y) + eu.z * fabsf(c.z) + sl * norm1(c);
-  const float E1 = eu.x * fabsf(pc.x) + eu.y * fabsf(pc.y) + eu.z * fabsf(pc.z) + sl * norm1(pc);
-  const float E2 = eu.x * fabsf(qc.x) + eu.y * fabsf(qc.y) + eu.z * fabsf(qc.z) + sl * norm1(qc);
-  const bool can_pos = (Ac + EA > 0.0f) && (nA0cam > -1e-18f) && (N1 + E1 > -1e-30f) && (N2 + E2 > -1e-30f);
-  const bool can_neg = (Ac - EA < 0.0f) && (nA0cam < 1e-18f) && (N1 - E1 < 1e-30f) && (N2 - E2 < 1e-30f);
-  const bool cW = fabsf(N1 + N2) - (E1 + E2) > (fabsf(Ac) + EA) * 1.000004f;
-  return (!can_pos && !can_neg) || cW;
-}
-
-// Can any jittered ray from `start` towards `dir` (+- jitter of half-width hh per axis) touch a
-// shadow-casting sphere?  Conservative: the line misses sphere (c,R) when |L x d| > R |d|; bound both
-// sides over the jitter box and leave 0.2 % + rounding slack for the reference's discriminant (:285).
-__device__ __forceinline__ bool spheres_maybe(const FrameParams& P, f3 start, f3 dir, float dlen, float hh) {
-  bool maybe = false;
-  const float jm = 1.7321f * hh;
-  for (int i = 0; i < P.nsph; ++i) {
-    const DevSphere& sp = P.sph[i];
-    if (sp.col[3] == -1.0f) continue;                    // glass casts no shadow, :279
-    const f3 Lv = start - mk(sp.cx, sp.cy, sp.cz);
-    const f3 cr = mk(Lv.y * dir.z - Lv.z * dir.y, Lv.z * dir.x - Lv.x * dir.z, Lv.x * dir.y - Lv.y * dir.x);
-    const float crn = sqrtf(dot3(cr, cr)), Ln = sqrtf(dot3(Lv, Lv)), R = sqrtf(fmaxf(sp.r2, 0.0f));
-    const bool miss = (crn - Ln * jm > R * (dlen + jm) * 1.002f) && (Ln < 1000.0f * R) && (sp.r2 > 0.0f);
-    maybe = maybe || !miss;
-  }
-  return maybe;
 }
 
 // Level 3 (lane = sample): TWO surface points ja, jb of one pixel (same jitter) per pass against the
