@@ -47,3 +47,23 @@ def test_mesh_casts_a_shadow_and_is_visible(scene, tmp_path):
     a0 = rt.RayTracer(cfg, scene).render(rot, cam, light, focal_for(cfg))
     a1 = rt.RayTracer(cfg, scene + rt.Scene.load_obj(path)).render(rot, cam, light, focal_for(cfg))
     assert 0.01 < (a0 != a1).mean() < 0.5
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_soups_tiled_kernel_equals_generic(seed):
+    """Random triangle soups of 70..330 triangles (slivers, degenerate, mirrors, glass) in the room: the tiled
+    wave kernel (default for n > 64) and the thread-per-pixel kernel must agree bit for bit."""
+    from test_gpu_cull import _random_scene, _render
+    rng = np.random.default_rng(7000 + seed)
+    scene = _random_scene(rng, int(rng.integers(70, 330)), box=bool(seed % 2))
+    kw = dict(width=96, height=72, aa_x=[1, 2, 4][seed % 3], aa_y=[1, 2, 2][seed % 3],
+              shadow_samples=[64, 8, 21][seed % 3], light_spread=[0.05, 0.25][seed % 2], max_bounces=[4, 10][seed % 2],
+              band_rows=[72, 8][seed % 2], band_index=[0, 1][seed % 2], band_count=[1, 3][seed % 2])
+    light = rng.uniform(-0.9, 0.9, 3).tolist()
+    cam = [float(rng.uniform(-0.4, 0.4)), float(rng.uniform(-0.4, 0.4)), -3.0]
+    rot = rt.rotation_matrix(float(rng.uniform(-0.3, 0.3)), float(rng.uniform(-0.3, 0.3)))
+    a0, f0 = _render(kw, 0, scene, rot, cam, light)
+    a2, f2 = _render(kw, abi.RT_FLAG_GENERIC_KERNEL, scene, rot, cam, light)
+    bad = np.argwhere(a0 != a2)
+    assert bad.size == 0, "tiled kernel differs in %d pixels, first at %s" % (len(bad), bad[0])
+    assert np.array_equal(f0.view(np.uint32), f2.view(np.uint32))
