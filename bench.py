@@ -35,9 +35,27 @@ WORKLOADS = {
     "headline": dict(width=4096, height=4096, aa_x=4, aa_y=2, shadow_samples=64),
     # configs[1]
     "cfg2": dict(width=1024, height=1024, aa_x=2, aa_y=2, shadow_samples=16, spheres=()),
+    # configs[2]: glass sphere + mirror wall, 1920x1080, 4xAA, recursion depth 5 (10 shadow rays: the reference's default)
+    "cfg3": dict(width=1920, height=1080, max_bounces=5),
+    # configs[4]: Loader.cpp-style OBJ mesh of ~100k triangles in the box, 2048x2048, 1 spp, 1 shadow ray, diffuse
+    "cfg5": dict(width=2048, height=2048, aa_x=1, aa_y=1, shadow_samples=1, spheres=()),
     # the reference exactly as shipped
     "reference": dict(width=1024, height=1024),
 }
+
+
+def build_scene(workload, rt):
+    """Cornell Box (LoadTestModel), plus what the named configuration adds to it."""
+    scene = rt.Scene.cornell_box()
+    if workload == "cfg3":      # back wall -> mirror (TestModelH.h:58)
+        scene = scene.with_color([8, 9], (1.0, 1.0, 1.0, 0.0))
+    if workload == "cfg5":      # synthetic OBJ in the syntax Loader.cpp accepts (bunny_200.obj is not in the reference)
+        import tempfile
+        from uob_raytracer_amd import meshgen
+        path = os.path.join(tempfile.mkdtemp(), "mesh_100k.obj")
+        meshgen.write_sphere_obj(path, 250, 201)
+        scene = scene + rt.Scene.load_obj(path)
+    return scene
 
 
 def main():
@@ -80,7 +98,7 @@ def main():
     W, H = wl["width"], wl["height"]
     band_rows = args.band_rows if world > 1 else H
     cfg = abi.make_config(band_rows=band_rows, band_index=rank, band_count=world, device=local_rank, **wl)
-    scene = rt.Scene.cornell_box()
+    scene = build_scene(args.workload, rt)
     tracer = rt.RayTracer(cfg, scene)
     rows = tracer.rows
     focal = 1100.0 * min(W, H) / 1024.0 * cfg.aa_x
@@ -208,8 +226,8 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "%s: Cornell Box %dx%d, %dx%d AA, %d shadow rays, %d spheres, <=%d bounces" % (
-            args.workload, W, H, cfg.aa_x, cfg.aa_y, cfg.shadow_samples, cfg.num_spheres, cfg.max_bounces),
+        "config": {"workload": "%s: Cornell Box %dx%d, %dx%d AA, %d shadow rays, %d spheres, <=%d bounces, %d triangles" % (
+            args.workload, W, H, cfg.aa_x, cfg.aa_y, cfg.shadow_samples, cfg.num_spheres, cfg.max_bounces, len(scene)),
             "parallelism": "row bands of %d over %d GPU(s) + RCCL gather" % (band_rows, world) if world > 1 else "1 GPU"},
         "kernel_ms_per_launch": kernel_ms,
         "traced_mrays_per_s": traced_rays / (ms_per_step * 1e-3) / 1e6,
@@ -223,7 +241,7 @@ def main():
                          "note": "algorithmic bytes = 4 B/pixel ARGB + 80 B/triangle per workgroup; <<1% by construction"},
     }
 
-    if world == 1 and not args.no_brute_force and total_exec:
+    if world == 1 and not args.no_brute_force and total_exec and args.workload == "headline":
         # the same frame with the interval cull switched off (every triangle tested for every surface point)
         bcfg = abi.make_config(flags=abi.RT_FLAG_NO_CULL, device=local_rank, **wl)
         bt = rt.RayTracer(bcfg, scene)
