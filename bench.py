@@ -261,7 +261,18 @@ def main():
                               "note": "RT_FLAG_NO_CULL: same kernel, all triangles tested for every surface point"}
         bt.close()
 
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world > 1:
+        # N > 1: no CPU baseline (it is reported at N=1 only); spot-check the gathered frame against the oracle
+        from oracle import pyref
+        rng = np.random.default_rng(12345)
+        pix = rng.choice(W * H, size=4000, replace=False).astype(np.int32)
+        v, n, c = scene.packed()
+        o_argb, _ = pyref.Oracle().render(abi.make_config(**wl), v, n, c, rot, cam, light, focal, pix=pix,
+                                          nthreads=min(len(os.sched_getaffinity(0)), 16))
+        got = frame.view(-1)[torch.from_numpy(pix.astype(np.int64)).to(dev)].cpu().numpy().view(np.uint32)
+        out["gathered_frame_matches_oracle_on_sample"] = bool(np.array_equal(got, o_argb))
+
+    if not args.no_cpu_baseline and world == 1:
         from oracle import pyref   # checker, used here only as the timed CPU baseline
         # the GPU box gives one-GPU jobs a 16-core share: never use more host threads than that
         cores = min(len(os.sched_getaffinity(0)), 16)
