@@ -137,22 +137,29 @@ __device__ __forceinline__ bool primary_clear(f3 duc, f3 eu, float dumax, f3 c, 
   return (!can_pos && !can_neg) || cW;
 }
 
-// Can any jittered ray from `start` towards `dir` (+- jitter of half-width hh per axis) touch a
-// shadow-casting sphere?  Conservative: the line misses sphere (c,R) when |L x d| > R |d|; bound both
-// sides over the jitter box and leave 0.2 % + rounding slack for the reference's discriminant (:285).
-__device__ __forceinline__ bool spheres_maybe(const FrameParams& P, f3 start, f3 dir, float dlen, float hh) {
+// Can any ray of a bundle — origin `o`, directions dir + e with |e|_2 <= jm — touch a sphere?  Conservative:
+// the line misses sphere (c,R) when |L x d| > R |d|; bound both sides over the bundle and leave 0.2 % for the
+// rounding of the reference's discriminant b*b - 4*a*c (kernels.cl:285, :214).  That rounding is at most
+// ~50*2^-24 * |d|^2 (|L|^2 + R^2), while the margin is worth 8*0.002 * R^2 |d|^2: rigorous for |L|/R < 73,
+// applied for |L|/R < 40; farther (or degenerate) spheres are simply always tested.  The condition is
+// homogeneous in d, so it holds for the normalised directions of primary rays as well.
+//   casters_only: skip glass spheres (they cast no shadow, :279); primary rays see every sphere.
+__device__ __forceinline__ bool sphere_bundle_maybe(const FrameParams& P, f3 o, f3 dir, float dlen, float jm, bool casters_only) {
   bool maybe = false;
-  const float jm = 1.7321f * hh;
   for (int i = 0; i < P.nsph; ++i) {
     const DevSphere& sp = P.sph[i];
-    if (sp.col[3] == -1.0f) continue;                    // glass casts no shadow, :279
-    const f3 Lv = start - mk(sp.cx, sp.cy, sp.cz);
+    if (casters_only && sp.col[3] == -1.0f) continue;
+    const f3 Lv = o - mk(sp.cx, sp.cy, sp.cz);
     const f3 cr = mk(Lv.y * dir.z - Lv.z * dir.y, Lv.z * dir.x - Lv.x * dir.z, Lv.x * dir.y - Lv.y * dir.x);
     const float crn = sqrtf(dot3(cr, cr)), Ln = sqrtf(dot3(Lv, Lv)), R = sqrtf(fmaxf(sp.r2, 0.0f));
-    const bool miss = (crn - Ln * jm > R * (dlen + jm) * 1.002f) && (Ln < 1000.0f * R) && (sp.r2 > 0.0f);
+    const bool miss = (crn - Ln * jm > R * (dlen + jm) * 1.002f) && (Ln < 40.0f * R) && (sp.r2 > 0.0f);
     maybe = maybe || !miss;
   }
   return maybe;
+}
+// shadow rays of one surface point: jitter of half-width hh per axis
+__device__ __forceinline__ bool spheres_maybe(const FrameParams& P, f3 start, f3 dir, float dlen, float hh) {
+  return sphere_bundle_maybe(P, start, dir, dlen, 1.7321f * hh, true);
 }
 
 }  // namespace
