@@ -68,6 +68,9 @@ def main():
     ap.add_argument("--cpu-sample-pixels", type=int, default=0, help="0 = auto (about 10-30 s of CPU work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-brute-force", action="store_true", help="skip the cull-off comparison leg (N=1 only)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="with one rank, still initialise the process group and run the band gather (exercises the "
+                         "RCCL calls of the N>1 flow on a one-GPU box)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 flow on a box with fewer GPUs than ranks (bands travel via host memory)")
     args = ap.parse_args()
@@ -87,8 +90,12 @@ def main():
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    collective = world > 1 or args.force_collective
+    if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
@@ -96,7 +103,7 @@ def main():
 
     wl = WORKLOADS[args.workload]
     W, H = wl["width"], wl["height"]
-    band_rows = args.band_rows if world > 1 else H
+    band_rows = args.band_rows if collective else H
     cfg = abi.make_config(band_rows=band_rows, band_index=rank, band_count=world, device=local_rank, **wl)
     scene = build_scene(args.workload, rt)
     tracer = rt.RayTracer(cfg, scene)
@@ -108,9 +115,9 @@ def main():
     stripe = torch.empty((rows, W), dtype=torch.int32, device=dev)
     gathered = None
     bands.check_partition(H, world, band_rows)
-    if world > 1 and rank == 0:
-        gathered = [torch.empty((rows, W), dtype=torch.int32, device=dev) for _ in range(world)]
-    frame = torch.empty((H, W), dtype=torch.int32, device=dev) if (rank == 0 and world > 1) else None
+    if collective and rank == 0:    # one [world, rows, W] receive buffer; the gather list is its slices
+        gathered = torch.empty((world, rows, W), dtype=torch.int32, device=dev)
+    frame = torch.empty((H, W), dtype=torch.int32, device=dev) if (rank == 0 and collective) else None
 
     def step(ev=None):
         # the HIP kernel, enqueued on torch's current stream through the C ABI
@@ -120,15 +127,15 @@ def main():
         if ev:
             ev[1].record()
         # N > 1: one RCCL gather of the finished bands + de-interleave on rank 0; N == 1: the stripe IS the frame
-        if args.backend == "gloo" and world > 1:
-            host = bands.gather_frame(stripe.cpu(), world, rank, band_rows)
+        if args.backend == "gloo" and collective:
+            host = bands.gather_frame(stripe.cpu(), world, rank, band_rows, force=True)
             if rank == 0:
                 frame.copy_(host)
-        else:
-            bands.gather_frame(stripe, world, rank, band_rows, gathered, frame)
+        elif collective:
+            bands.gather_frame(stripe, world, rank, band_rows, gathered, frame, force=True)
 
     def sync():
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -162,7 +169,7 @@ def main():
     keys, xkeys = list(work), list(executed)
     stats = torch.tensor([elapsed, kernel_ms] + [float(work[k]) for k in keys] + [float(executed[k]) for k in xkeys],
                          dtype=torch.float64, device=dev)
-    if world > 1:
+    if collective:
         mx = stats[:2].clone()
         reduce_(mx, dist.ReduceOp.MAX)
         sm = stats[2:].clone()
@@ -175,11 +182,11 @@ def main():
 
     # frame integrity: rank 0 sums the final frame (N=1: the stripe is the frame)
     if rank == 0:
-        final = stripe if world == 1 else frame
+        final = frame if collective else stripe
         frame_sum = int(final.to(torch.int64).bitwise_and(0xFFFFFFFF).sum().item())
 
     if rank != 0:
-        if world > 1:
+        if collective:
             dist.destroy_process_group()
         return
 
@@ -228,7 +235,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": "%s: Cornell Box %dx%d, %dx%d AA, %d shadow rays, %d spheres, <=%d bounces, %d triangles" % (
             args.workload, W, H, cfg.aa_x, cfg.aa_y, cfg.shadow_samples, cfg.num_spheres, cfg.max_bounces, len(scene)),
-            "parallelism": "row bands of %d over %d GPU(s) + RCCL gather" % (band_rows, world) if world > 1 else "1 GPU"},
+            "parallelism": "row bands of %d over %d GPU(s) + RCCL gather" % (band_rows, world) if collective else "1 GPU"},
         "kernel_ms_per_launch": kernel_ms,
         "traced_mrays_per_s": traced_rays / (ms_per_step * 1e-3) / 1e6,
         "nominal_rays_per_frame": nominal_rays, "traced_rays_per_frame": traced_rays,
@@ -241,7 +248,7 @@ def main():
                          "note": "algorithmic bytes = 4 B/pixel ARGB + 80 B/triangle per workgroup; <<1% by construction"},
     }
 
-    if world == 1 and not args.no_brute_force and total_exec and args.workload == "headline":
+    if not collective and not args.no_brute_force and total_exec and args.workload == "headline":
         # the same frame with the interval cull switched off (every triangle tested for every surface point)
         bcfg = abi.make_config(flags=abi.RT_FLAG_NO_CULL, device=local_rank, **wl)
         bt = rt.RayTracer(bcfg, scene)
@@ -261,7 +268,21 @@ def main():
                               "note": "RT_FLAG_NO_CULL: same kernel, all triangles tested for every surface point"}
         bt.close()
 
-    if not args.no_cpu_baseline and world > 1:
+    if not collective:
+        # the drop-in call itself (rt_render = offload_rendering): kernel + blocking read-back into host memory
+        host_frame = np.empty((H, W), np.uint32)
+        host_frame.fill(0)                       # touch the pages once, as a live screen->buffer would be
+        tracer.render(rot, cam, light, focal, out=host_frame)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            tracer.render(rot, cam, light, focal, out=host_frame)
+        pms = (time.perf_counter() - t0) / 3 * 1e3
+        out["host_buffer_path"] = {"ms_per_frame": pms, "value": nominal_rays / (pms * 1e-3) / 1e6, "unit": "Mrays/s",
+                                   "identical_frame": bool(np.array_equal(host_frame.view(np.int32), stripe.cpu().numpy())),
+                                   "note": "rt_render with a pageable host framebuffer (PCIe read-back included); "
+                                           "never the headline value"}
+
+    if not args.no_cpu_baseline and collective:
         # N > 1: no CPU baseline (it is reported at N=1 only); spot-check the gathered frame against the oracle
         from oracle import pyref
         rng = np.random.default_rng(12345)
@@ -272,7 +293,7 @@ def main():
         got = frame.view(-1)[torch.from_numpy(pix.astype(np.int64)).to(dev)].cpu().numpy().view(np.uint32)
         out["gathered_frame_matches_oracle_on_sample"] = bool(np.array_equal(got, o_argb))
 
-    if not args.no_cpu_baseline and world == 1:
+    if not args.no_cpu_baseline and not collective:
         from oracle import pyref   # checker, used here only as the timed CPU baseline
         # the GPU box gives one-GPU jobs a 16-core share: never use more host threads than that
         cores = min(len(os.sched_getaffinity(0)), 16)
@@ -295,12 +316,34 @@ def main():
                                "sample": "%d random pixels of the same %dx%d frame (%.3g nominal rays), CPU oracle "
                                          "(oracle/rt_oracle.c, OpenMP, %d threads)" % (
                                              npx, W, H, npx * aa * (1 + cfg.shadow_samples), cores)}
+        # the reference kernel itself (oracle/_ref, built from the reference's kernels.cl for x86-64), where it can
+        # express the workload; for the headline (4x2 AA is not expressible) its 2x2-AA variant next to the port
+        refv = {"reference": "default", "cfg2": "cfg2", "headline": "s64_4096"}.get(args.workload)
+        if refv and pyref.have_ref(refv) and len(scene) == 26:
+            rk = pyref.RefKernel(refv)
+            rcfg = full if refv != "s64_4096" else abi.make_config(**dict(wl, aa_x=2, aa_y=2))
+            raa = rcfg.aa_x * rcfg.aa_y
+            rfocal = 1100.0 * min(W, H) / 1024.0 * rcfg.aa_x
+            rpix = pix[:max(2000, min(npx, int(npx * aa / raa / 2)))]
+            t0 = time.perf_counter()
+            r_argb, _ = rk.render(v, n, c, rot, cam, light, rfocal, pix=rpix, nthreads=cores, want_rgb=False)
+            rdt = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            p_argb, _ = orc.render(rcfg, v, n, c, rot, cam, light, rfocal, pix=rpix, nthreads=cores)
+            pdt = time.perf_counter() - t0
+            rrays = rpix.size * raa * (1 + rcfg.shadow_samples)
+            out["cpu_baseline"]["reference_kernel"] = {
+                "value": rrays / rdt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "reference", "seconds": rdt,
+                "sample": "%d random pixels, %dx%d, %dx%d AA, %d shadow rays: the reference's kernels.cl compiled for "
+                          "x86-64 (oracle/_ref/libref_%s.so)" % (rpix.size, W, H, rcfg.aa_x, rcfg.aa_y, rcfg.shadow_samples, refv),
+                "port_on_same_sample": rrays / pdt / 1e6,
+                "port_matches_reference_kernel": bool(np.array_equal(r_argb, p_argb))}
         # the sampled pixels double as an in-bench parity check of the frame just timed
         got = (stripe if world == 1 else frame).view(-1)[torch.from_numpy(pix.astype(np.int64)).to(dev)].cpu().numpy().view(np.uint32)
         out["cpu_baseline"]["gpu_frame_matches_oracle_on_sample"] = bool(np.array_equal(got, o_argb))
 
     print(json.dumps(out))
-    if world > 1:
+    if collective:
         dist.destroy_process_group()
 
 

@@ -21,25 +21,27 @@ def check_partition(height, world, band_rows):
                          % (height, band_rows * world))
 
 
-def gather_frame(stripe, world, rank, band_rows, gather_list=None, frame=None, dst=0):
+def gather_frame(stripe, world, rank, band_rows, recv=None, frame=None, dst=0, force=False):
     """Gather every rank's packed bands to `dst` and de-interleave them into image order.
 
-    stripe: [rows_owned, W] integer tensor (ARGB words) on this rank.  Returns the [H, W] frame on `dst`
-    (written into `frame` when given) and None elsewhere.  With world == 1 the stripe is the frame.
+    stripe: [rows_owned, W] integer tensor (ARGB words) on this rank.  `recv`: optional preallocated
+    [world, rows_owned, W] receive buffer on `dst` (its slices are the gather list, so the bands land in one
+    allocation and the de-interleave is a single strided copy).  Returns the [H, W] frame on `dst` (written
+    into `frame` when given) and None elsewhere.  With world == 1 the stripe is the frame and no collective
+    runs, unless `force` (used to exercise the collective on one rank).
     """
     import torch
     import torch.distributed as dist
-    if world == 1:
+    if world == 1 and not force:
         return stripe
     rows, width = stripe.shape
-    if rank == dst and gather_list is None:
-        gather_list = [torch.empty_like(stripe) for _ in range(world)]
-    dist.gather(stripe, gather_list if rank == dst else None, dst=dst)
+    if rank == dst and recv is None:
+        recv = torch.empty((world, rows, width), dtype=stripe.dtype, device=stripe.device)
+    dist.gather(stripe, [recv[r] for r in range(world)] if rank == dst else None, dst=dst)
     if rank != dst:
         return None
     if frame is None:
         frame = torch.empty((rows * world, width), dtype=stripe.dtype, device=stripe.device)
     # [rank, band, row, x] -> [band, rank, row, x] == image order
-    g = torch.stack(gather_list).view(world, -1, band_rows, width)
-    frame.view(-1, world, band_rows, width).copy_(g.permute(1, 0, 2, 3))
+    frame.view(-1, world, band_rows, width).copy_(recv.view(world, -1, band_rows, width).permute(1, 0, 2, 3))
     return frame

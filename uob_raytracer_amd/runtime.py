@@ -168,10 +168,13 @@ class RayTracer:
         return (np.ascontiguousarray(rot, np.float32), np.ascontiguousarray(cam, np.float32)[:3].copy(),
                 np.ascontiguousarray(light, np.float32)[:3].copy())
 
-    def render(self, rot, cam, light, focal, want_rgb=False):
-        """Blocking render + readback.  Returns ARGB [rows,W] (and the float4 tap [rows,W,4])."""
+    def render(self, rot, cam, light, focal, want_rgb=False, out=None):
+        """Blocking render + readback.  Returns ARGB [rows,W] (and the float4 tap [rows,W,4]).
+        `out`: optional C-contiguous uint32 [rows,W] array to receive the frame (screen->buffer)."""
         rot, cam, light = self._args(rot, cam, light)
-        argb = np.zeros((self.rows, self.width), np.uint32)
+        if out is not None and (out.dtype != np.uint32 or out.shape != (self.rows, self.width) or not out.flags.c_contiguous):
+            raise ValueError("out must be a C-contiguous uint32 array of shape (%d, %d)" % (self.rows, self.width))
+        argb = out if out is not None else np.zeros((self.rows, self.width), np.uint32)
         rgb = np.zeros((self.rows, self.width, 4), np.float32) if want_rgb else None
         _check(lib().rt_render(self._h, _fp(rot), _fp(cam), _fp(light), C.c_float(focal),
                                argb.ctypes.data_as(C.POINTER(C.c_uint32)), _fp(rgb) if want_rgb else None))
