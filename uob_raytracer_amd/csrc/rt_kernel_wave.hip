@@ -231,7 +231,14 @@ constexpr int kWavesPerBlock = RT_WAVES_PER_BLOCK;
     prof[slot] += now_ - tlast;                                                     \
     tlast = now_;                                                                   \
   }
-template <bool CULL, bool COUNT, bool PROF = false>
+// STRIDE > 0: the LDS record arrays have a fixed stride of STRIDE triangles (n <= STRIDE) and the whole LDS
+// layout is static, so every array base is an immediate of the ds_read instead of a VGPR; 0 = packed by n.
+template <int STRIDE, bool CULL>
+__host__ __device__ constexpr int wave_fixed_lds_float4() {
+  return kLdsRecords * STRIDE + STRIDE / 4 + 4 * STRIDE + kWavesPerBlock * wave_lds_bytes(CULL) / 16;
+}
+
+template <bool CULL, bool COUNT, bool PROF = false, int STRIDE = 0>
 // 5 waves per SIMD (<= 96 VGPRs, 36 B/lane of scratch spills): the kernel is bound by instruction issue
 // latency at low occupancy, 5 waves measured 11.3 ms vs 12.4 ms unconstrained (4 waves) and 11.5 ms at 6
 #ifndef RT_MIN_WAVES
@@ -240,14 +247,17 @@ template <bool CULL, bool COUNT, bool PROF = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wave(const FrameParams P) {
   unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tlast = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
-  extern __shared__ float4 lds[];
+  extern __shared__ float4 lds_dyn[];
+  __shared__ float4 lds_fix[STRIDE ? wave_fixed_lds_float4<STRIDE ? STRIDE : 4, CULL>() : 1];
+  float4* const lds = STRIDE ? lds_fix : lds_dyn;
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int n = P.n, ns = P.n_shadow;
+  const int st = STRIDE ? STRIDE : n, sst = STRIDE ? STRIDE : ns;     // record-array strides
 
   // ---- stage the triangle list once per workgroup ---------------------------------------------------
-  stage_triangles(P, lds, tid, 64 * kWavesPerBlock);
-  int* sidx = reinterpret_cast<int*>(lds + kLdsRecords * n);          // shadow-casting triangles, in order
+  stage_triangles(P, lds, tid, 64 * kWavesPerBlock, st);
+  int* sidx = reinterpret_cast<int*>(lds + kLdsRecords * st);         // shadow-casting triangles, in order
   if (wave == 0) {                                                    // n <= 64 on this path (supports())
     const bool casts = (lane < n) && (P.colors[lane < n ? lane : 0].w != -1.0f);   // glass casts no shadow, :247
     const unsigned long long m = ballot(casts);
@@ -257,16 +267,16 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
   __syncthreads();
   // the shadow-casting triangles' (v0,e1,e2,c) once more, in caster order: levels 2 and 3 index them by
   // the bit position of the candidate mask, with no index indirection in their dependent chains
-  float4* scbase = reinterpret_cast<float4*>(sidx + ((n + 3) & ~3));
+  float4* scbase = reinterpret_cast<float4*>(sidx + ((st + 3) & ~3));
   for (int kq = tid; kq < ns; kq += 64 * kWavesPerBlock) {
     const int ti = sidx[kq];
-    scbase[kq] = lds[ti]; scbase[ns + kq] = lds[n + ti]; scbase[2 * ns + kq] = lds[2 * n + ti]; scbase[3 * ns + kq] = lds[3 * n + ti];
+    scbase[kq] = lds[ti]; scbase[sst + kq] = lds[st + ti]; scbase[2 * sst + kq] = lds[2 * st + ti]; scbase[3 * sst + kq] = lds[3 * st + ti];
   }
   __syncthreads();
-  const ShadowCasters SC{scbase, scbase + ns, scbase + 2 * ns, scbase + 3 * ns};
-  const WaveLds L = wave_lds(reinterpret_cast<char*>(scbase + 4 * ns) + wave * wave_lds_bytes(CULL), CULL);
+  const ShadowCasters SC{scbase, scbase + sst, scbase + 2 * sst, scbase + 3 * sst};
+  const WaveLds L = wave_lds(reinterpret_cast<char*>(scbase + 4 * sst) + wave * wave_lds_bytes(CULL), CULL);
 
-  const LdsScene S = lds_scene(lds, n);
+  const LdsScene S = lds_scene(lds, n, st);
   const int aa = P.aa_x * P.aa_y;                                     // a power of two <= 64 (supports())
   const int la = __builtin_ctz(aa);
   const int PT = 64 >> la;                                            // pixels per task
@@ -513,6 +523,7 @@ template __global__ void rt_draw_wave<true, false>(const FrameParams);
 template __global__ void rt_draw_wave<false, true>(const FrameParams);
 template __global__ void rt_draw_wave<true, true>(const FrameParams);
 template __global__ void rt_draw_wave<true, false, true>(const FrameParams);
+template __global__ void rt_draw_wave<true, false, false, 32>(const FrameParams);
 
 bool wave_kernel_supports(const FrameParams& P) {
   const int aa = P.aa_x * P.aa_y;
@@ -551,7 +562,8 @@ void launch_wave(const FrameParams& P, bool cull, bool count, hipStream_t stream
     if (cull) hipLaunchKernelGGL((rt_draw_wave<true, true>), grid, block, lds_bytes, stream, P);
     else hipLaunchKernelGGL((rt_draw_wave<false, true>), grid, block, lds_bytes, stream, P);
   } else {
-    if (cull) hipLaunchKernelGGL((rt_draw_wave<true, false>), grid, block, lds_bytes, stream, P);
+    if (cull && P.n <= 32) hipLaunchKernelGGL((rt_draw_wave<true, false, false, 32>), grid, block, 0, stream, P);
+    else if (cull) hipLaunchKernelGGL((rt_draw_wave<true, false>), grid, block, lds_bytes, stream, P);
     else hipLaunchKernelGGL((rt_draw_wave<false, false>), grid, block, lds_bytes, stream, P);
   }
 }

@@ -18,15 +18,20 @@ struct LdsScene {
 };
 constexpr int kLdsRecords = 8;
 
-__device__ __forceinline__ LdsScene lds_scene(const float4* lds, int n) {
-  return LdsScene{lds, lds + n, lds + 2 * n, lds + 3 * n, lds + 4 * n, lds + 5 * n, lds + 6 * n, lds + 7 * n, n};
+// `stride` = distance between the record arrays in float4 (n when packed; a compile-time constant >= n lets
+// the compiler fold every array base into the ds_read offset field)
+__device__ __forceinline__ LdsScene lds_scene(const float4* lds, int n, int stride) {
+  const int s = stride;
+  return LdsScene{lds, lds + s, lds + 2 * s, lds + 3 * s, lds + 4 * s, lds + 5 * s, lds + 6 * s, lds + 7 * s, n};
 }
+__device__ __forceinline__ LdsScene lds_scene(const float4* lds, int n) { return lds_scene(lds, n, n); }
 
 // Triangles that fit one LDS stage (8 records of 16 B each, 64 KB)
 constexpr int kLdsMaxTriangles = 512;
 
-__device__ __forceinline__ void stage_triangles(const FrameParams& P, float4* lds, long tid, long nthreads) {
+__device__ __forceinline__ void stage_triangles(const FrameParams& P, float4* lds, long tid, long nthreads, int stride = 0) {
   const int n = P.n;
+  const int s = stride ? stride : n;
   const f3 cam = mk(P.cam[0], P.cam[1], P.cam[2]);
   for (long i = tid; i < n; i += nthreads) {
     const float4 a = P.verts[3 * i], b = P.verts[3 * i + 1], c = P.verts[3 * i + 2];
@@ -35,13 +40,13 @@ __device__ __forceinline__ void stage_triangles(const FrameParams& P, float4* ld
     const f3 bc = cam - v0;
     const f3 pc = cof(bc, e2), qc = cof(e1, bc);
     lds[i] = make_float4(v0.x, v0.y, v0.z, 0.f);
-    lds[n + i] = make_float4(e1.x, e1.y, e1.z, 0.f);
-    lds[2 * n + i] = make_float4(e2.x, e2.y, e2.z, 0.f);
-    lds[3 * n + i] = make_float4(cf.x, cf.y, cf.z, detc(bc, cf));
-    lds[4 * n + i] = P.normals[i];
-    lds[5 * n + i] = P.colors[i];
-    lds[6 * n + i] = make_float4(pc.x, pc.y, pc.z, 0.f);
-    lds[7 * n + i] = make_float4(qc.x, qc.y, qc.z, 0.f);
+    lds[s + i] = make_float4(e1.x, e1.y, e1.z, 0.f);
+    lds[2 * s + i] = make_float4(e2.x, e2.y, e2.z, 0.f);
+    lds[3 * s + i] = make_float4(cf.x, cf.y, cf.z, detc(bc, cf));
+    lds[4 * s + i] = P.normals[i];
+    lds[5 * s + i] = P.colors[i];
+    lds[6 * s + i] = make_float4(pc.x, pc.y, pc.z, 0.f);
+    lds[7 * s + i] = make_float4(qc.x, qc.y, qc.z, 0.f);
   }
 }
 
