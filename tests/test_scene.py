@@ -44,13 +44,31 @@ def test_obj_loader_errors(tmp_path):
     bad.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 9\n")          # index out of range
     with pytest.raises(rt.RtError):
         rt.Scene.load_obj(str(bad))
-    slash = tmp_path / "slash.obj"
-    slash.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1/1 2/2 3/3\n")   # syntax the reference cannot parse either
-    with pytest.raises(rt.RtError):
-        rt.Scene.load_obj(str(slash))
+    for text in ("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2\n", "v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 x\n",
+                 "v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 -4\n", "v 0 0\n"):
+        bad.write_text(text)
+        with pytest.raises(rt.RtError):
+            rt.Scene.load_obj(str(bad))
     empty = tmp_path / "empty.obj"
     empty.write_text("# nothing\n")
     assert len(rt.Scene.load_obj(str(empty))) == 0
+
+
+def test_obj_loader_hardening_beyond_the_reference(tmp_path):
+    """Slash tokens, relative indices and polygons: the reference reads garbage on these
+    (Loader.cpp:44-45 extracts three plain ints); here they give the triangles the plain syntax would."""
+    verts = "v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0.5\n"
+    plain = tmp_path / "plain.obj"
+    plain.write_text(verts + "f 1 2 3\nf 1 3 4\n")
+    want = rt.Scene.load_obj(str(plain)).aos
+    for faces in ("f 1/1/1 2/2/2 3/3/3\nf 1//7 3//8 4//9\n",      # v/vt/vn and v//vn
+                  "f 1/1 2/2 3/3 4/4\n",                          # a quad, fan-triangulated (1 2 3), (1 3 4)
+                  "f -4 -3 -2\nf -4 -2 -1\n",                     # relative indices
+                  "f 1 2 3 4   # trailing comment\r\n"):
+        p = tmp_path / "variant.obj"
+        p.write_text(verts + faces)
+        got = rt.Scene.load_obj(str(p)).aos
+        assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32)), faces
 
 
 def test_scene_concatenation_like_reference_main(scene):

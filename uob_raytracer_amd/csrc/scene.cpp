@@ -137,24 +137,48 @@ int rt_scene_load_obj(const char* path, rt_triangle* out, int32_t cap) {
       if (sscanf(line + used, "%f %f %f", &x, &y, &z) != 3) { rc = RT_E_IO; break; }
       verts.push_back(P3{1.5f * x, 1.5f * y, 1.5f * z});        // Loader.cpp:42
     } else if (!strcmp(tag, "f")) {
-      int a, b, c;
-      if (sscanf(line + used, "%d %d %d", &a, &b, &c) != 3) { rc = RT_E_IO; break; }
+      // Loader.cpp:44-45 reads three plain 1-based indices.  Hardening beyond the reference (which reads
+      // garbage there): "i/t/n" and "i//n" tokens (the vertex index is taken), negative = relative indices,
+      // and polygons with more than three corners, fan-triangulated in order.
+      int idx[64];
+      int k = 0;
       const int nv = (int)verts.size();
-      if (a < 1 || b < 1 || c < 1 || a > nv || b > nv || c > nv) { rc = RT_E_IO; break; }
-      if (n < cap) {
-        rt_triangle t;
-        set_tri(&t, verts[a - 1], verts[b - 1], verts[c - 1], kObjBlue);
-        rt_triangle_compute_normal(&t);                          // normal of the UN-negated triangle, :46
-        float* vs[3] = {t.v0, t.v1, t.v2};
-        for (float* v : vs) {                                    // (-1)*v + (-0.4, 1.15, -0.7, 1), :48-52
-          v[0] = (-1.f) * v[0] + -0.4f;
-          v[1] = (-1.f) * v[1] + 1.15f;
-          v[2] = (-1.f) * v[2] + -0.7f;
-          v[3] = (-1.f) * v[3] + 1.0f;
+      const char* p = line + used;
+      bool bad = false;
+      for (;;) {
+        while (*p == ' ' || *p == '\t') ++p;
+        if (*p == '\0' || *p == '\n' || *p == '\r' || *p == '#') break;
+        char* end = nullptr;
+        long v = strtol(p, &end, 10);
+        if (end == p || k == 64) { bad = true; break; }
+        p = end;
+        while (*p && *p != ' ' && *p != '\t' && *p != '\n' && *p != '\r') {      // "/t/n" suffix
+          if (*p != '/' && *p != '-' && (*p < '0' || *p > '9')) { bad = true; break; }
+          ++p;
         }
-        out[n] = t;
+        if (bad) break;
+        if (v < 0) v = nv + 1 + v;
+        if (v < 1 || v > nv) { bad = true; break; }
+        idx[k++] = (int)v;
       }
-      ++n;
+      if (bad || k < 3) { rc = RT_E_IO; break; }
+      for (int j = 1; j + 1 < k; ++j) {
+        const int a = idx[0], b = idx[j], c = idx[j + 1];
+        if (n < cap) {
+          rt_triangle t;
+          set_tri(&t, verts[a - 1], verts[b - 1], verts[c - 1], kObjBlue);
+          rt_triangle_compute_normal(&t);                          // normal of the UN-negated triangle, :46
+          float* vs[3] = {t.v0, t.v1, t.v2};
+          for (float* v : vs) {                                    // (-1)*v + (-0.4, 1.15, -0.7, 1), :48-52
+            v[0] = (-1.f) * v[0] + -0.4f;
+            v[1] = (-1.f) * v[1] + 1.15f;
+            v[2] = (-1.f) * v[2] + -0.7f;
+            v[3] = (-1.f) * v[3] + 1.0f;
+          }
+          out[n] = t;
+        }
+        ++n;
+      }
     }
   }
   fclose(f);
