@@ -62,6 +62,8 @@ typedef struct rt_config {
 #define RT_FLAG_GENERIC_KERNEL 2u   /* always use the one-thread-per-pixel kernel (A/B and parity tests)  */
 #define RT_FLAG_NO_CULL 4u          /* wave kernel: test every triangle for every surface point (no interval
                                        culling); output is bit-identical either way                        */
+#define RT_FLAG_NO_TILE_BINS 8u     /* mesh kernel (n > 64): visit every 64-triangle tile instead of the per-frame
+                                       candidate-tile masks; output is bit-identical either way                */
 
 typedef struct rt_ctx rt_ctx;
 
@@ -112,7 +114,11 @@ int rt_count_work(rt_ctx* ctx, const float rot[12], const float cam[3], const fl
  * samples were tested (level 3), out[1] = first-stage (t) sample-test passes = 64 sample tests each,
  * out[2] = second-stage (u,v) passes, out[3] = wave-wide sphere evaluations, out[4] = lit surface points
  * decided fully lit by the interval bounds, out[5] = 64-ray tasks that needed no sampling at all,
- * out[6..7] = 0.                                                                                        */
+ * out[6..7] = 0.
+ * Meshes (n > 64, tiled kernel): out[0] = (wave, tile) visits of the primary pass, out[1] = triangles left by
+ * the primary bound over those visits, out[2] = (wave, tile) visits of the shadow pass, out[3] = triangles
+ * left by level 1, out[4] = level-3 point-pair calls, out[5] = their first-stage passes, out[7] = task
+ * rounds per wave summed over waves.                                                                       */
 int rt_count_executed(rt_ctx* ctx, const float rot[12], const float cam[3], const float light[3],
                       float focal, uint64_t out[8]);
 

@@ -17,7 +17,8 @@ pytestmark = pytest.mark.gpu
     (24, 16, dict(width=80, height=60, aa_x=2, aa_y=2, shadow_samples=64, light_spread=0.3)),     # wide penumbrae
     (12, 9, dict(width=70, height=41, aa_x=4, aa_y=2, shadow_samples=10, spheres=())),            # ragged frame
 ])
-@pytest.mark.parametrize("flags", [0, abi.RT_FLAG_GENERIC_KERNEL])     # tiled wave kernel / thread-per-pixel kernel
+# tiled wave kernel with per-frame candidate-tile masks / the same visiting every tile / thread-per-pixel kernel
+@pytest.mark.parametrize("flags", [0, abi.RT_FLAG_NO_TILE_BINS, abi.RT_FLAG_GENERIC_KERNEL])
 def test_box_plus_mesh_vs_oracle(n_lon, n_lat, kw, flags, scene, oracle, tmp_path):
     path = str(tmp_path / "mesh.obj")
     nf = meshgen.write_sphere_obj(path, n_lon, n_lat)
@@ -63,7 +64,31 @@ def test_random_soups_tiled_kernel_equals_generic(seed):
     cam = [float(rng.uniform(-0.4, 0.4)), float(rng.uniform(-0.4, 0.4)), -3.0]
     rot = rt.rotation_matrix(float(rng.uniform(-0.3, 0.3)), float(rng.uniform(-0.3, 0.3)))
     a0, f0 = _render(kw, 0, scene, rot, cam, light)
+    a1, f1 = _render(kw, abi.RT_FLAG_NO_TILE_BINS, scene, rot, cam, light)
     a2, f2 = _render(kw, abi.RT_FLAG_GENERIC_KERNEL, scene, rot, cam, light)
     bad = np.argwhere(a0 != a2)
     assert bad.size == 0, "tiled kernel differs in %d pixels, first at %s" % (len(bad), bad[0])
     assert np.array_equal(f0.view(np.uint32), f2.view(np.uint32))
+    assert np.array_equal(a1, a2) and np.array_equal(f1.view(np.uint32), f2.view(np.uint32))
+
+
+@pytest.mark.parametrize("case", range(4))
+def test_tile_masks_never_change_a_pixel(case, scene, tmp_path):
+    """Bigger meshes (tens of tiles), lights inside / far outside the scene box, a camera inside the mesh's
+    silhouette, bands: candidate-tile masks on == off, bit for bit."""
+    from test_gpu_cull import _render
+    path = str(tmp_path / "mesh.obj")
+    meshgen.write_sphere_obj(path, [60, 90, 48, 72][case], [40, 60, 36, 50][case])
+    both = scene + rt.Scene.load_obj(path)
+    kw = [dict(width=160, height=128, aa_x=1, aa_y=1, shadow_samples=1),
+          dict(width=128, height=96, aa_x=2, aa_y=2, shadow_samples=8, light_spread=0.2),
+          dict(width=200, height=130, aa_x=2, aa_y=1, shadow_samples=16, band_rows=10, band_index=2, band_count=3),
+          dict(width=144, height=144, aa_x=1, aa_y=1, shadow_samples=64, light_spread=0.6, spheres=())][case]
+    light = [[0.0, -0.5, -0.7], [-0.45, 0.8, -0.55], [3.0, -4.0, -6.0], [-0.4, 0.2, -0.5]][case]
+    cam = [[0.0, 0.0, -3.2], [0.2, 0.3, -2.0], [-0.3, 0.6, -1.4], [0.0, 0.0, -3.2]][case]
+    rot = rt.rotation_matrix([0.0, 0.2, -0.3, 0.0][case], [0.0, -0.1, 0.2, 0.0][case])
+    a0, f0 = _render(kw, 0, both, rot, cam, light)
+    a1, f1 = _render(kw, abi.RT_FLAG_NO_TILE_BINS, both, rot, cam, light)
+    bad = np.argwhere(a0 != a1)
+    assert bad.size == 0, "tile masks changed %d pixels, first at %s" % (len(bad), bad[0])
+    assert np.array_equal(f0.view(np.uint32), f1.view(np.uint32))

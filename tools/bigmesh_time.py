@@ -6,9 +6,12 @@ n_lon, n_lat, W = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 path = os.path.join(tempfile.mkdtemp(), "m.obj")
 nf = meshgen.write_sphere_obj(path, n_lon, n_lat)
 scene = rt.Scene.cornell_box() + rt.Scene.load_obj(path)
-cfg = abi.make_config(width=W, height=W, aa_x=1, aa_y=1, shadow_samples=1, light_spread=0.0)
+cfg = abi.make_config(width=W, height=W, aa_x=1, aa_y=1, shadow_samples=1, spheres=() if os.environ.get("NOSPH", "1") == "1" else abi.REFERENCE_SPHERES)   # configs[4] as bench.py --workload cfg5
 tr = rt.RayTracer(cfg, scene)
 rot, cam, light = rt.rotation_matrix(0, 0), [0, 0, -3.2], [0, -0.5, -0.7]
 for i in range(2):
     t = time.time(); a = tr.render(rot, cam, light, 1100.0 * W / 1024); dt = time.time() - t
     print("triangles", len(scene), "size", W, "kernel ms %.1f" % tr.last_kernel_ms(), "wall %.3f s" % dt, "nonblack", float((a != 0xFF000000).mean()), flush=True)
+if len(sys.argv) > 4:
+    for k, v in tr.count_executed(rot, cam, light, 1100.0 * W / 1024).items():
+        print("  %-28s %d" % (k, v))

@@ -7,6 +7,7 @@ RT_OK, RT_E_INVALID, RT_E_DEVICE, RT_E_NOMEM, RT_E_IO, RT_E_UNSUPPORTED = 0, -1,
 RT_FLAG_FAST_MATH = 1
 RT_FLAG_GENERIC_KERNEL = 2
 RT_FLAG_NO_CULL = 4
+RT_FLAG_NO_TILE_BINS = 8
 
 
 class RtSphere(C.Structure):

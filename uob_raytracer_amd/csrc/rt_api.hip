@@ -34,8 +34,10 @@ void set_error(const char* fmt, ...) {
 void launch_generic(const FrameParams& P, bool count, hipStream_t stream);
 bool generic_needs_records(int n);
 void launch_stage_records(const FrameParams& P, hipStream_t stream);
-void launch_mesh(const FrameParams& P, hipStream_t stream);
+void launch_mesh(const FrameParams& P, bool count, hipStream_t stream);
 bool mesh_kernel_supports(const FrameParams& P);
+int mesh_tiles(int n);
+int mesh_screen_cells(int pixels);
 void launch_wave(const FrameParams& P, bool cull, bool count, hipStream_t stream);
 void launch_wave_prof(const FrameParams& P, hipStream_t stream);
 bool wave_kernel_supports(const FrameParams& P);
@@ -53,6 +55,8 @@ using namespace uobrt;
     }                                                                                   \
   } while (0)
 
+constexpr int kWorldGrid = 32;       // world cells per axis of the mesh kernel's shadow-ray tile masks
+
 struct rt_ctx {
   rt_config cfg;
   int device = 0;
@@ -64,6 +68,10 @@ struct rt_ctx {
   unsigned long long* d_counters = nullptr;
   unsigned int* d_jobctr = nullptr; // wave kernel's job counter
   float4* d_records = nullptr;     // staged records in HBM for meshes beyond one LDS stage
+  // mesh kernel: per-frame candidate-tile masks (rt_kernel_mesh.hip) and the scene's bounding box for its world grid
+  unsigned long long *d_screen_masks = nullptr, *d_world_masks = nullptr;
+  int nwords = 0, scx = 0, scy = 0;
+  float box_lo[3] = {0, 0, 0}, box_hi[3] = {0, 0, 0};
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
@@ -160,6 +168,29 @@ int rt_init(const rt_config* cfg, const float* vertices4, const float* normals4,
   if (n > 64 && hipMalloc(&c->d_records, (size_t)n * 8 * sizeof(float4)) != hipSuccess) {
     set_error("hipMalloc failed: %s", hipGetErrorString(hipGetLastError())); return fail(RT_E_NOMEM);
   }
+  if (n > 64 && !(cfg->flags & (RT_FLAG_NO_TILE_BINS | RT_FLAG_NO_CULL | RT_FLAG_GENERIC_KERNEL))) {
+    c->nwords = (mesh_tiles(n) + 63) / 64;
+    c->scx = mesh_screen_cells(cfg->width); c->scy = mesh_screen_cells(cfg->height);
+    const size_t g3 = (size_t)kWorldGrid * kWorldGrid * kWorldGrid;
+    if (hipMalloc(&c->d_screen_masks, (size_t)c->scx * c->scy * c->nwords * 8) != hipSuccess ||
+        hipMalloc(&c->d_world_masks, g3 * c->nwords * 8) != hipSuccess) {
+      set_error("hipMalloc failed: %s", hipGetErrorString(hipGetLastError())); return fail(RT_E_NOMEM);
+    }
+    // every surface point lies on a triangle or a sphere: their bounding box (the world grid spans it)
+    for (int k = 0; k < 3; ++k) { c->box_lo[k] = 3.0e38f; c->box_hi[k] = -3.0e38f; }
+    for (size_t v = 0; v < (size_t)n * 3; ++v)
+      for (int k = 0; k < 3; ++k) {
+        c->box_lo[k] = fminf(c->box_lo[k], vertices4[4 * v + k]);
+        c->box_hi[k] = fmaxf(c->box_hi[k], vertices4[4 * v + k]);
+      }
+    for (int i = 0; i < cfg->num_spheres; ++i) {
+      const float r = sqrtf(fmaxf(cfg->spheres[i].radius_sq, 0.0f)) * 1.0001f + 1e-6f;
+      for (int k = 0; k < 3; ++k) {
+        c->box_lo[k] = fminf(c->box_lo[k], cfg->spheres[i].center[k] - r);
+        c->box_hi[k] = fmaxf(c->box_hi[k], cfg->spheres[i].center[k] + r);
+      }
+    }
+  }
   if (hipStreamCreate(&c->stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
     set_error("stream/event creation failed"); return fail(RT_E_DEVICE);
   }
@@ -201,6 +232,22 @@ static void fill_params(const rt_ctx* c, const float rot[12], const float cam[3]
   P->job_counter = c->d_jobctr;
   P->nseg = (g.width + 63) / 64;
   P->njobs = P->nseg * c->owned_rows;
+  if (c->d_screen_masks) {
+    P->screen_masks = c->d_screen_masks; P->world_masks = c->d_world_masks;
+    P->nwords = c->nwords; P->scx = c->scx; P->scy = c->scy; P->grid_g = kWorldGrid;
+    // World grid: a cube over the scene box, grown so that every shadow-ray start point X + 1e-4 (light - X)
+    // of a surface point X in the box (kernels.cl:324) stays inside, rounding included.
+    float ext = 0.0f, dmax = 0.0f, amax = 0.0f;
+    for (int k = 0; k < 3; ++k) {
+      ext = fmaxf(ext, c->box_hi[k] - c->box_lo[k]);
+      dmax = fmaxf(dmax, fmaxf(fabsf(light[k] - c->box_lo[k]), fabsf(light[k] - c->box_hi[k])));
+      amax = fmaxf(amax, fmaxf(fabsf(c->box_lo[k]), fabsf(c->box_hi[k])));
+    }
+    const float grow = 2e-4f * dmax + 1e-4f * (1.0f + amax) + 1e-3f * ext;
+    for (int k = 0; k < 3; ++k) P->grid_lo[k] = c->box_lo[k] - grow;
+    P->grid_cell = (ext + 2.0f * grow) / (float)kWorldGrid;
+    P->grid_inv = 1.0f / P->grid_cell;
+  }
 }
 
 static int launch_frame(rt_ctx* c, const float rot[12], const float cam[3], const float light[3], float focal,
@@ -221,7 +268,7 @@ static int launch_frame(rt_ctx* c, const float rot[12], const float cam[3], cons
     launch_wave(P, !(c->cfg.flags & RT_FLAG_NO_CULL), false, stream);
   } else if (wave_paths && !(c->cfg.flags & RT_FLAG_NO_CULL) && mesh_kernel_supports(P)) {
     launch_stage_records(P, stream);        // per frame: the records hold camera-dependent terms
-    launch_mesh(P, stream);
+    launch_mesh(P, false, stream);
   } else {
     launch_generic(P, false, stream);
   }
@@ -277,14 +324,17 @@ int rt_count_executed(rt_ctx* c, const float rot[12], const float cam[3], const 
   if (c->owned_rows == 0) return RT_OK;
   FrameParams P;
   fill_params(c, rot, cam, light, focal, &P);
-  if ((c->cfg.flags & RT_FLAG_GENERIC_KERNEL) || !wave_kernel_supports(P)) {
+  const bool generic = (c->cfg.flags & RT_FLAG_GENERIC_KERNEL) != 0;
+  const bool mesh = !generic && !wave_kernel_supports(P) && !(c->cfg.flags & RT_FLAG_NO_CULL) && mesh_kernel_supports(P);
+  if (generic || (!wave_kernel_supports(P) && !mesh)) {
     set_error("rt_count_executed: this configuration runs on the generic kernel, whose executed work is rt_count_work");
     return RT_E_UNSUPPORTED;
   }
   P.counters = c->d_counters;
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(rt_work), c->stream));
-  if (getenv("UOB_RT_PHASE_PROFILE")) launch_wave_prof(P, c->stream);   // diagnostic: s_memtime per phase
+  if (mesh) { launch_stage_records(P, c->stream); launch_mesh(P, true, c->stream); }
+  else if (getenv("UOB_RT_PHASE_PROFILE")) launch_wave_prof(P, c->stream);   // diagnostic: s_memtime per phase
   else launch_wave(P, !(c->cfg.flags & RT_FLAG_NO_CULL), true, c->stream);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(out, c->d_counters, sizeof(rt_work), hipMemcpyDeviceToHost, c->stream));
@@ -308,6 +358,7 @@ void rt_destroy(rt_ctx* c) {
   if (c->ev1) hipEventDestroy(c->ev1);
   hipFree(c->d_verts); hipFree(c->d_normals); hipFree(c->d_colors);
   hipFree(c->d_argb); hipFree(c->d_rgb); hipFree(c->d_counters); hipFree(c->d_records); hipFree(c->d_jobctr);
+  hipFree(c->d_screen_masks); hipFree(c->d_world_masks);
   delete c;
 }
 

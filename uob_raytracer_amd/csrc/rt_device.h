@@ -37,6 +37,11 @@ struct FrameParams {
   unsigned int* job_counter;   // wave kernel: next 64-pixel segment to hand out (zeroed before each launch)
   int32_t njobs, nseg;    // segments in total / per row
   float4* records;        // staged triangle records in HBM (8 x n float4), used when n exceeds one LDS stage
+  // mesh kernel: per-frame candidate-tile masks (rt_kernel_mesh.hip), nullptr = visit every tile
+  unsigned long long* screen_masks;   // [scy][scx][nwords]: tiles a primary ray through that 64x64-pixel cell may hit
+  unsigned long long* world_masks;    // [G][G][G][nwords]: tiles that may shadow a surface point inside that world cell
+  int32_t nwords, scx, scy, grid_g;   // 64-bit words per mask; screen cells per row / column; world cells per axis
+  float grid_lo[3], grid_cell, grid_inv;   // world grid: origin, cell edge, 1 / cell edge
 };
 
 // Map a packed local row index to the global image row (band partition, include/uob_rt.h rt_config).

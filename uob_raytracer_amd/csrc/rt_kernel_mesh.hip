@@ -27,6 +27,24 @@ namespace {
 
 constexpr int kTile = 64;                   // triangles per LDS tile
 constexpr int kMeshWaves = 4;               // waves (= tasks) per workgroup sharing a tile
+constexpr int kDirectSamples = 2;           // up to this many, level 2 is skipped as well (the test is cheaper than its bound)
+constexpr int kPointSamples = 8;            // up to this many shadow samples, level 3 runs lane = surface point
+constexpr int kScreenCell = 64;             // pixels per side of a screen cell of the primary-ray tile masks
+constexpr int kScreenCellLog = 6;
+
+__device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
+  return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+         (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+
+// World cell of a shadow ray's start point (rt_bin_shadow bounds exactly the points that map to a cell)
+__device__ __forceinline__ int world_cell(const FrameParams& P, f3 s) {
+  const int g1 = P.grid_g - 1;
+  int ix = (int)floorf((s.x - P.grid_lo[0]) * P.grid_inv), iy = (int)floorf((s.y - P.grid_lo[1]) * P.grid_inv),
+      iz = (int)floorf((s.z - P.grid_lo[2]) * P.grid_inv);
+  ix = ix < 0 ? 0 : (ix > g1 ? g1 : ix); iy = iy < 0 ? 0 : (iy > g1 ? g1 : iy); iz = iz < 0 ? 0 : (iz > g1 ? g1 : iz);
+  return (iz * P.grid_g + iy) * P.grid_g + ix;
+}
 
 struct MeshWaveLds {
   float4* h0;   // start.xyz | radius_sq
@@ -46,7 +64,7 @@ struct Mask2 { unsigned long long a, b; };
 __device__ __forceinline__ Mask2 tile_test_pair(const float4* tv0, const float4* te1, const float4* te2, const float4* tc,
                                                 const MeshWaveLds& L, int ja, int jb, unsigned long long K,
                                                 unsigned long long need, f3 jit, unsigned long long active,
-                                                unsigned long long sha, unsigned long long shb) {
+                                                unsigned long long sha, unsigned long long shb, unsigned long long& iters) {
   const float4 ha0 = L.h0[ja], ha1 = L.h1[ja], hb0 = L.h0[jb], hb1 = L.h1[jb];     // LDS broadcasts
   const f3 sa = mk(ha0.x, ha0.y, ha0.z), sb = mk(hb0.x, hb0.y, hb0.z);
   const float ra = ha0.w, rb = hb0.w;
@@ -55,6 +73,7 @@ __device__ __forceinline__ Mask2 tile_test_pair(const float4* tv0, const float4*
   int pos = 0;
   for (unsigned long long kk = K; kk != 0ull; kk &= kk - 1ull, ++pos) {
     if (((need >> pos) & 1ull) == 0ull) continue;
+    ++iters;
     const int k = __builtin_ctzll(kk);
     const f3 v0 = xyz(tv0[k]), e1 = xyz(te1[k]), e2 = xyz(te2[k]), c = xyz(tc[k]);
     const f3 ba = sa - v0, bb = sb - v0;
@@ -119,8 +138,118 @@ __device__ __forceinline__ void generate_streams(const FrameParams& P, const Mes
 
 }  // namespace
 
+// ---- per-frame candidate-tile masks --------------------------------------------------------------------
+// The exact bounds of rt_wave_common.h are certificates about a SET of rays ("no ray of the set can make the
+// reference's test accept this triangle"); what holds for a set holds for every subset.  So the same bounds,
+// evaluated once per frame for coarse sets, tell every task which 64-triangle tiles it may skip WITHOUT
+// loading them:
+//   rt_bin_primary : set = all primary rays through a 64x64-pixel screen cell  -> screen_masks[cell] bit t
+//   rt_bin_shadow  : set = all shadow rays whose start point lies in a world-grid cell (any lit surface point
+//                    there, any jitter sample)                                  -> world_masks[cell] bit t
+// bit t = "some triangle of tile t is not certified clear".  A workgroup ORs the masks of the cells its rays
+// belong to and walks only the set bits; inside a tile the per-task levels 1-3 run as before.
+// One wave per tile (lane = triangle, registers hold its record), looping over the cells.
+__global__ __launch_bounds__(64 * kMeshWaves) void rt_bin_primary(const FrameParams P) {
+  const int lane = threadIdx.x & 63;
+  const int n = P.n, ntiles = (n + kTile - 1) / kTile;
+  const int t = blockIdx.x * kMeshWaves + (threadIdx.x >> 6);
+  if (t >= ntiles) return;
+  const int gi = t * kTile + lane;
+  const bool ok = gi < n;
+  const size_t g = ok ? gi : t * kTile;
+  const float4 c4 = P.records[(size_t)3 * n + g];
+  const f3 c = xyz(c4), pc = xyz(P.records[(size_t)6 * n + g]), qc = xyz(P.records[(size_t)7 * n + g]);
+  const f3 r0 = mk(P.rot[0], P.rot[1], P.rot[2]), r1 = mk(P.rot[4], P.rot[5], P.rot[6]), r2 = mk(P.rot[8], P.rot[9], P.rot[10]);
+  const int cy = blockIdx.y;
+  const int ylo = cy * kScreenCell, yhi = (ylo + kScreenCell - 1) < P.H ? (ylo + kScreenCell - 1) : (P.H - 1);
+  // sub-pixel rectangle of the cell, in the units of primary_ray() (rt_trace.h)
+  const float Ylo = ((float)(ylo * P.aa_y) - ((float)P.H * (float)P.aa_y) / 2.0f) * P.sy;
+  const float Yhi = ((float)(yhi * P.aa_y + P.aa_y - 1) - ((float)P.H * (float)P.aa_y) / 2.0f) * P.sy;
+  const float hy = 0.5f * (Yhi - Ylo);
+  for (int cx = 0; cx < P.scx; ++cx) {
+    const int xlo = cx * kScreenCell, xhi = (xlo + kScreenCell - 1) < P.W ? (xlo + kScreenCell - 1) : (P.W - 1);
+    const float Xlo = (float)(xlo * P.aa_x) - ((float)P.W * (float)P.aa_x) / 2.0f;
+    const float Xhi = (float)(xhi * P.aa_x + P.aa_x - 1) - ((float)P.W * (float)P.aa_x) / 2.0f;
+    const float hx = 0.5f * (Xhi - Xlo);
+    const f3 wc = mk(Xlo + hx, Ylo + hy, P.focal);
+    const f3 duc = mk(dot3(r0, wc), dot3(r1, wc), dot3(r2, wc));
+    const f3 eu = mk(1.0001f * (fabsf(r0.x) * hx + fabsf(r0.y) * hy), 1.0001f * (fabsf(r1.x) * hx + fabsf(r1.y) * hy),
+                     1.0001f * (fabsf(r2.x) * hx + fabsf(r2.y) * hy));
+    const float dumax = fmaxf(fmaxf(fabsf(duc.x) + eu.x, fabsf(duc.y) + eu.y), fabsf(duc.z) + eu.z);
+    const bool clear = (dumax < 1e30f) && primary_clear(duc, eu, dumax, c, c4.w, pc, qc);
+    const unsigned long long m = ballot(ok && !clear);
+    if (m != 0ull && lane == 0)
+      atomicOr(&P.screen_masks[((size_t)cy * P.scx + cx) * P.nwords + (t >> 6)], 1ull << (t & 63));
+  }
+}
+
+// Grid: x = tiles / 4, y = z-slice of the world grid.
+__global__ __launch_bounds__(64 * kMeshWaves) void rt_bin_shadow(const FrameParams P) {
+  const int lane = threadIdx.x & 63;
+  const int n = P.n, ntiles = (n + kTile - 1) / kTile;
+  const int t = blockIdx.x * kMeshWaves + (threadIdx.x >> 6);
+  if (t >= ntiles) return;
+  const int gi = t * kTile + lane;
+  const size_t g = gi < n ? gi : t * kTile;
+  const bool ok = gi < n && P.records[(size_t)5 * n + g].w != -1.0f;          // glass casts no shadow, :247
+  TriLane T1;
+  T1.v0 = xyz(P.records[g]); T1.e1 = xyz(P.records[(size_t)n + g]); T1.e2 = xyz(P.records[(size_t)2 * n + g]);
+  T1.c = xyz(P.records[(size_t)3 * n + g]);
+  T1.c1 = norm1(T1.c); T1.e1_1 = norm1(T1.e1); T1.e2_1 = norm1(T1.e2);
+  const f3 light = mk(P.light[0], P.light[1], P.light[2]);
+  const float linf = fmaxf(fmaxf(fabsf(light.x), fabsf(light.y)), fabsf(light.z));
+  const float hbox = P.spread / 2.f;
+  const float half = 0.5f * P.grid_cell;
+  const int G = P.grid_g, Gc = G >> 1, izc = blockIdx.y;            // grid.y = coarse z-slices (G is even)
+  const float tv0inf = fmaxf(fmaxf(fabsf(T1.v0.x), fabsf(T1.v0.y)), fabsf(T1.v0.z));
+  // every start point that world_cell() maps to the cell with centre C and half edge h lies in C +- hs
+  // (slack: the rounding of that mapping); its dir = light - X (kernels.cl:323) = (light - C) + (C - X),
+  // |C - X| <= hs + 1e-4 |dir|  (start = X + 1e-4 dir, :324)
+  auto cell_clear = [&](f3 C, float h) {
+    const float cinf = fmaxf(fmaxf(fabsf(C.x), fabsf(C.y)), fabsf(C.z));
+    const float hs = 1.001f * h + 1e-5f * (1.0f + cinf);
+    const f3 D0 = light - C;
+    const float d0len = sqrtf(dot3(D0, D0));
+    const float dinf = fmaxf(fmaxf(fabsf(D0.x), fabsf(D0.y)), fabsf(D0.z));
+    const float ed = hs + 1.1e-4f * (d0len + 2.0f * hs) + 1e-6f * (1.0f + dinf + cinf);
+    const float dlen_max = (d0len + 1.7321f * ed) * 1.00001f;
+    const float dlen_min = fmaxf(d0len - 1.7321f * ed, 0.0f) * 0.99999f;
+    const float hh = 1.002f * hbox + 2e-6f * (dlen_max + hbox);
+    return light_bundle_bound(T1, light, C, hs, D0, ed, hh, dlen_min, dlen_max, linf + tv0inf + dlen_max).clear;
+  };
+  // two levels: a coarse cell of 2x2x2 cells first (what is clear for the union is clear for each of them)
+  for (int iyc = 0; iyc < Gc; ++iyc)
+    for (int ixc = 0; ixc < Gc; ++ixc) {
+      const f3 Cc = mk(P.grid_lo[0] + ((float)ixc + 0.5f) * (2.0f * P.grid_cell), P.grid_lo[1] + ((float)iyc + 0.5f) * (2.0f * P.grid_cell),
+                       P.grid_lo[2] + ((float)izc + 0.5f) * (2.0f * P.grid_cell));
+      if (ballot(ok && !cell_clear(Cc, 2.0f * half)) == 0ull) continue;
+      for (int sub = 0; sub < 8; ++sub) {
+        const int ix = 2 * ixc + (sub & 1), iy = 2 * iyc + ((sub >> 1) & 1), iz = 2 * izc + (sub >> 2);
+        const f3 C = mk(P.grid_lo[0] + ((float)ix + 0.5f) * P.grid_cell, P.grid_lo[1] + ((float)iy + 0.5f) * P.grid_cell,
+                        P.grid_lo[2] + ((float)iz + 0.5f) * P.grid_cell);
+        const unsigned long long m = ballot(ok && !cell_clear(C, half));
+        if (m != 0ull && lane == 0)
+          atomicOr(&P.world_masks[((size_t)(iz * G + iy) * G + ix) * P.nwords + (t >> 6)], 1ull << (t & 63));
+      }
+    }
+}
+
 // Grid: x = ceil(W/16), y = ceil(owned_rows/16); block = 4 waves = 2x2 blocks of 8x8 pixels.
+// COUNT: diagnostic build that also sums what the waves executed into P.counters[0..7] (rt_count_executed)
+// PROF: diagnostic build (never timed) that sums s_memtime cycles per phase over the waves instead
+#define MESH_STAMP(slot)                                                            \
+  if (PROF) {                                                                       \
+    unsigned long long now_;                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                              \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_) :: "memory"); \
+    __builtin_amdgcn_sched_barrier(0);                                              \
+    xw[slot] += now_ - tlast;                                                       \
+    tlast = now_;                                                                   \
+  }
+template <bool COUNT, bool PROF = false>
 __global__ __launch_bounds__(64 * kMeshWaves) void rt_draw_mesh(const FrameParams P) {
+  unsigned long long xw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
   extern __shared__ float4 lds[];
   float4* tile = lds;                                   // 8 records x kTile triangles
   const int tid = threadIdx.x;
@@ -129,6 +258,28 @@ __global__ __launch_bounds__(64 * kMeshWaves) void rt_draw_mesh(const FrameParam
                       reinterpret_cast<float4*>(reinterpret_cast<char*>(lds + 8 * kTile) + wave * kMeshWaveLdsBytes + 64 * 16),
                       reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(lds + 8 * kTile) + wave * kMeshWaveLdsBytes + 64 * 32)};
   const int n = P.n, ntiles = (n + kTile - 1) / kTile;
+  const int nwords = (ntiles + 63) >> 6;
+  // candidate-tile masks of this workgroup: primary rays (fixed for the frame), shadow rays (per task round)
+  unsigned long long* pmask = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(lds + 8 * kTile) +
+                                                                    kMeshWaves * kMeshWaveLdsBytes);
+  unsigned long long* smask = pmask + nwords;
+  const bool bins = P.screen_masks != nullptr;
+  for (int w = tid; w < nwords; w += 64 * kMeshWaves) {
+    unsigned long long m = bins ? 0ull : ~0ull;
+    if (bins) {
+      const int cx = (blockIdx.x * 16) >> kScreenCellLog;
+      int last = -1;
+      for (int r = 0; r < 16; ++r) {                      // the workgroup's 16 packed rows: global y may jump at a band edge
+        const int lrr = blockIdx.y * 16 + r;
+        if (lrr >= P.owned_rows) break;
+        const int cy = band_global_row(lrr, P.band_rows, P.band_index, P.band_count) >> kScreenCellLog;
+        if (cy != last) m |= P.screen_masks[((size_t)cy * P.scx + cx) * nwords + w];
+        last = cy;
+      }
+    }
+    pmask[w] = m;
+  }
+  __syncthreads();
   const LdsScene G = lds_scene(P.records, n);           // the whole mesh, in HBM (hit finalisation, bounce rays)
   const float4 *t_v0 = tile, *t_e1 = tile + kTile, *t_e2 = tile + 2 * kTile, *t_c = tile + 3 * kTile,
                *t_col = tile + 5 * kTile, *t_pc = tile + 6 * kTile, *t_qc = tile + 7 * kTile;
@@ -193,11 +344,17 @@ __global__ __launch_bounds__(64 * kMeshWaves) void rt_draw_mesh(const FrameParam
               1.0001f * (fabsf(r2.x) * hx + fabsf(r2.y) * hy));
       dumax = fmaxf(fmaxf(fabsf(duc.x) + eu.x, fabsf(duc.y) + eu.y), fabsf(duc.z) + eu.z);
     }
+    MESH_STAMP(0)
     float current_t = RT_MAXFLOAT, bu = 0.f, bv = 0.f;
     int best = -1;
     const f3 ndp = -ray.dir;
-    for (int t = 0; t < ntiles; ++t) {
+    for (int w = 0; w < nwords; ++w)
+    for (unsigned long long tm = uniform64(pmask[w]); tm != 0ull; tm &= tm - 1ull) {
+      const int t = w * 64 + __builtin_ctzll(tm);
+      if (t >= ntiles) break;
+      MESH_STAMP(2)
       load_tile(t);
+      MESH_STAMP(1)
       const int nc = (n - t * kTile) < kTile ? (n - t * kTile) : kTile;
       unsigned long long Kp = nc == 64 ? ~0ull : ((1ull << nc) - 1ull);
       {
@@ -205,6 +362,7 @@ __global__ __launch_bounds__(64 * kMeshWaves) void rt_draw_mesh(const FrameParam
         const bool clear = primary_clear(duc, eu, dumax, xyz(c4), c4.w, xyz(t_pc[lane]), xyz(t_qc[lane]));
         if (dumax < 1e30f) Kp &= ~ballot(clear);
       }
+      if (COUNT) { xw[0]++; xw[1] += __popcll(Kp); }
       if (valid) {
         for (unsigned long long m = Kp; m != 0ull; m &= m - 1ull) {
           const int i = __builtin_ctzll(m);
@@ -219,6 +377,7 @@ __global__ __launch_bounds__(64 * kMeshWaves) void rt_draw_mesh(const FrameParam
         }
       }
     }
+    MESH_STAMP(2)
     bool lit = false, secondary = false;
     if (valid) {
       if (best >= 0) {
@@ -253,7 +412,7 @@ __global__ __launch_bounds__(64 * kMeshWaves) void rt_draw_mesh(const FrameParam
     const float dk = dlen * 1.000004f;
     const unsigned long long sphmask = ballot(lit && P.nsph > 0 && spheres_maybe(P, start, dir, dlen, hh));
     f3 s0 = mk(0.f, 0.f, 0.f), D0 = mk(0.f, 0.f, 0.f);
-    float es = 0.f, ed = 0.f, dlen_max = 0.f, dlen_min = 0.f, hh_task = 0.f;
+    float es = 0.f, ed = 0.f, dlen_max = 0.f, dlen_min = 0.f, hh_task = 0.f, m_task = 0.f;
     bool task_ok = false;
     if (litmask != 0ull) {
       const int jr = __builtin_ctzll(litmask);
@@ -266,12 +425,46 @@ __global__ __launch_bounds__(64 * kMeshWaves) void rt_draw_mesh(const FrameParam
       dlen_min = wave_min(lit ? dlen : 3.0e38f);
       task_ok = (ballot(lit && !sane) == 0ull) && es < 1e30f && ed < 1e30f;
       hh_task = 1.002f * hbox + 2e-6f * (dlen_max + hbox);
+      m_task = fmaxf(fmaxf(fabsf(light.x), fabsf(light.y)), fabsf(light.z)) + dlen_max;
+    }
+    // this lane's pixel's xorshift stream after the seed call (kernels.cl:319), for the point-parallel level 3
+    uint32_t rs0 = 0u, rs1 = 0u, rs2 = 0u;
+    if (NS <= kPointSamples) {
+      const int gid = pixel_global_id(P, x, y);
+      rs0 = xorshift((uint32_t)gid); rs1 = xorshift((uint32_t)((float)gid * 91.0f)); rs2 = xorshift((uint32_t)((float)gid * 19.0f));
     }
     unsigned long long my_sh = 0ull;            // blocked samples of THIS lane's surface point, across tiles
     bool blocked = false, task_blocked = false;
     int rng_group = -1;                         // which pixel group's streams the scratch currently holds
-    for (int t = 0; t < ntiles; ++t) {
+    // candidate tiles of the workgroup's four tasks: OR of the world-cell masks of their lit surface points
+    __syncthreads();
+    for (int w = tid; w < nwords; w += 64 * kMeshWaves) smask[w] = 0ull;
+    __syncthreads();
+    if (litmask != 0ull) {
+      if (!bins || ballot(lit && !sane) != 0ull) {
+        for (int w = lane; w < nwords; w += 64) atomicOr(&smask[w], ~0ull);
+      } else {
+        const int ci = world_cell(P, start);
+        for (unsigned long long rem = litmask; rem != 0ull;) {
+          const int cj = __builtin_amdgcn_readlane(ci, __builtin_ctzll(rem));
+          rem &= ~ballot(ci == cj);
+          const unsigned long long* src = P.world_masks + (size_t)cj * nwords;
+          for (int w = lane; w < nwords; w += 64) {
+            const unsigned long long v = src[w];
+            if (v != 0ull) atomicOr(&smask[w], v);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    MESH_STAMP(3)
+    for (int w = 0; w < nwords; ++w)
+    for (unsigned long long tm = uniform64(smask[w]); tm != 0ull; tm &= tm - 1ull) {
+      const int t = w * 64 + __builtin_ctzll(tm);
+      if (t >= ntiles) break;
+      MESH_STAMP(7)
       load_tile(t);
+      MESH_STAMP(4)
       if (litmask == 0ull || task_blocked) continue;            // wave-uniform; the barriers are behind us
       const int nc = (n - t * kTile) < kTile ? (n - t * kTile) : kTile;
       const unsigned long long casts = ballot(lane < nc && t_col[lane].w != -1.0f);    // glass casts no shadow, :247
@@ -280,20 +473,66 @@ __global__ __launch_bounds__(64 * kMeshWaves) void rt_draw_mesh(const FrameParam
         TriLane T1;
         T1.v0 = xyz(t_v0[lane]); T1.e1 = xyz(t_e1[lane]); T1.e2 = xyz(t_e2[lane]); T1.c = xyz(t_c[lane]);
         T1.c1 = norm1(T1.c); T1.e1_1 = norm1(T1.e1); T1.e2_1 = norm1(T1.e2);
-        const Bound tb = task_bound(T1, s0, D0, es, ed, hh_task, dlen_min, dlen_max);
+        const Bound tb = light_bundle_bound(T1, light, s0, es, D0, ed, hh_task, dlen_min, dlen_max, m_task + norm1(T1.v0));
         K = casts & ~ballot(tb.clear);
         if ((casts & ballot(tb.all_blocked)) != 0ull) { task_blocked = true; continue; }
       }
+      MESH_STAMP(5)
+      if (COUNT) { xw[2]++; xw[3] += __popcll(K); xw[6] += (K == casts && __popcll(casts) > 32) ? 1 : 0; }
       if (K == 0ull) continue;
       unsigned long long need = 0ull;                              // level 2, lane = surface point
       int pos = 0;
-      for (unsigned long long kk = K; kk != 0ull; kk &= kk - 1ull, ++pos) {
+      // with one or two samples per point the bound costs more than the samples: test every candidate
+      if (NS <= kDirectSamples) need = ~0ull;
+      else for (unsigned long long kk = K; kk != 0ull; kk &= kk - 1ull, ++pos) {
         const int kq = __builtin_ctzll(kk);
         const Bound pb = point_bound(start, dir, hh, dlen, dminlen, dk, xyz(t_v0[kq]), xyz(t_e1[kq]), xyz(t_e2[kq]), xyz(t_c[kq]));
         if (!pb.clear || !sane) need |= 1ull << pos;
         blocked = blocked || (sane && pb.all_blocked);
       }
-      const unsigned long long work = ballot(lit && !blocked && need != 0ull && (my_sh & active) != active);
+      MESH_STAMP(6)
+      const bool mine = lit && !blocked && need != 0ull && (my_sh & active) != active;
+      const unsigned long long work = ballot(mine);
+      if (NS <= kPointSamples) {
+        // level 3 with few samples, lane = surface point: every lane runs the reference's test (kernels.cl:251-272)
+        // for its own point, sample after sample, against the tile triangles its `need` names — one pass serves
+        // 64 points (lane = sample would keep NS of 64 lanes busy)
+        if (work != 0ull) {
+          uint32_t r0 = rs0, r1 = rs1, r2 = rs2;
+          for (int sm = 0; sm < NS; ++sm) {
+            r0 = xorshift(r0); r1 = xorshift(r1); r2 = xorshift(r2);                     // rand = random(rand), :331
+            const bool todo = mine && ((my_sh >> sm) & 1ull) == 0ull;
+            if (ballot(todo) == 0ull) continue;
+            const f3 d = dir + mk(crush1(r0, P.spread), crush1(r1, P.spread), crush1(r2, P.spread));   // :333
+            const f3 nd = -d;
+            bool hit = false;
+            int pos2 = 0;
+            for (unsigned long long kk = K; kk != 0ull; kk &= kk - 1ull, ++pos2) {
+              const bool go = todo && !hit && ((need >> pos2) & 1ull) != 0ull;
+              if (ballot(go) == 0ull) continue;
+              if (COUNT) xw[5]++;
+              const int kq = __builtin_ctzll(kk);
+              if (go) {
+                const f3 v0 = xyz(t_v0[kq]), c = xyz(t_c[kq]);
+                const f3 b = start - v0;
+                const float detA_recip = rcp_exact(detc(nd, c));
+                const float tt = detc(b, c) * detA_recip;
+                const f3 dv = tt * d;
+                const float dist = dv.x * dv.x + dv.y * dv.y + dv.z * dv.z;
+                if (tt >= 0 && dist < radius_sq) {
+                  const f3 e1 = xyz(t_e1[kq]), e2 = xyz(t_e2[kq]);
+                  const float u = detc(nd, cof(b, e2)) * detA_recip;
+                  const float v = detc(nd, cof(e1, b)) * detA_recip;
+                  if (u >= 0 && v >= 0 && (u + v) <= 1) hit = true;
+                }
+              }
+            }
+            if (hit) my_sh |= 1ull << sm;
+          }
+          if (COUNT) xw[4]++;
+        }
+        continue;
+      }
       for (int g = 0; g * GL < 64 && work != 0ull; ++g) {          // level 3, lane = shadow sample
         const unsigned long long gm = (work >> (g * GL)) & (GL == 64 ? ~0ull : ((1ull << GL) - 1ull));
         if (gm == 0ull) continue;
@@ -310,7 +549,8 @@ __global__ __launch_bounds__(64 * kMeshWaves) void rt_draw_mesh(const FrameParam
             const int j2 = pm != 0ull ? base + __builtin_ctzll(pm) : j;
             pm &= pm - 1ull;
             const Mask2 m2 = tile_test_pair(t_v0, t_e1, t_e2, t_c, L, j, j2, K, readlane64(need, j) | readlane64(need, j2), jit,
-                                            active, readlane64(my_sh, j), readlane64(my_sh, j2));
+                                            active, readlane64(my_sh, j), readlane64(my_sh, j2), xw[5]);
+            if (COUNT) xw[4]++;
             if (lane == j2) my_sh = m2.b;
             if (lane == j) my_sh = m2.a;
           }
@@ -366,9 +606,15 @@ __global__ __launch_bounds__(64 * kMeshWaves) void rt_draw_mesh(const FrameParam
       if (ok == k) outc = v;
     }
   }
+  MESH_STAMP(7)
+  if (PROF) { if (lane == 0) for (int q = 0; q < 8; ++q) atomicAdd(&P.counters[q], xw[q]); return; }
+  if (COUNT) {
+    xw[7] = aa;
+    if (lane == 0) for (int q = 0; q < 8; ++q) if (xw[q]) atomicAdd(&P.counters[q], xw[q]);
+  }
   const int x = B.x0 + (lane & 7);
   const int lr = B.lr0 + (lane >> 3);
-  if (lr < P.owned_rows && x < P.W) {
+  if (!COUNT && !PROF && lr < P.owned_rows && x < P.W) {      // the counting pass has no framebuffer
     const float inv = (float)aa;
     const f3 c = mk(outc.x / inv, outc.y / inv, outc.z / inv);
     const size_t o = (size_t)lr * P.W + x;
@@ -383,11 +629,24 @@ bool mesh_kernel_supports(const FrameParams& P) {
          P.spread >= 0.0f;
 }
 
-void launch_mesh(const FrameParams& P, hipStream_t stream) {
+int mesh_tiles(int n) { return (n + kTile - 1) / kTile; }
+int mesh_screen_cells(int pixels) { return (pixels + kScreenCell - 1) / kScreenCell; }
+
+// P.records must hold this frame's records (launch_stage_records) before the masks are built.
+void launch_mesh(const FrameParams& P, bool count, hipStream_t stream) {
   const dim3 block(64 * kMeshWaves);
+  const int ntiles = mesh_tiles(P.n), nwords = (ntiles + 63) / 64;
+  if (P.screen_masks != nullptr) {
+    hipMemsetAsync(P.screen_masks, 0, (size_t)P.scx * P.scy * nwords * 8, stream);
+    hipMemsetAsync(P.world_masks, 0, (size_t)P.grid_g * P.grid_g * P.grid_g * nwords * 8, stream);
+    hipLaunchKernelGGL(rt_bin_primary, dim3((ntiles + kMeshWaves - 1) / kMeshWaves, P.scy), block, 0, stream, P);
+    hipLaunchKernelGGL(rt_bin_shadow, dim3((ntiles + kMeshWaves - 1) / kMeshWaves, P.grid_g / 2), block, 0, stream, P);
+  }
   const dim3 grid((P.W + 15) / 16, (P.owned_rows + 15) / 16);
-  const size_t lds_bytes = 8 * kTile * sizeof(float4) + kMeshWaves * (size_t)kMeshWaveLdsBytes;
-  hipLaunchKernelGGL(rt_draw_mesh, grid, block, lds_bytes, stream, P);
+  const size_t lds_bytes = 8 * kTile * sizeof(float4) + kMeshWaves * (size_t)kMeshWaveLdsBytes + 2 * (size_t)nwords * 8;
+  if (count && getenv("UOB_RT_PHASE_PROFILE")) hipLaunchKernelGGL((rt_draw_mesh<false, true>), grid, block, lds_bytes, stream, P);
+  else if (count) hipLaunchKernelGGL((rt_draw_mesh<true>), grid, block, lds_bytes, stream, P);
+  else hipLaunchKernelGGL((rt_draw_mesh<false>), grid, block, lds_bytes, stream, P);
 }
 
 }  // namespace uobrt

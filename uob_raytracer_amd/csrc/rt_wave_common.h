@@ -88,6 +88,54 @@ __device__ __forceinline__ Bound task_bound(const TriLane& T, f3 s0, f3 D0, floa
   return r;
 }
 
+// The same question asked from the LIGHT's side (rt_kernel_mesh.hip: level 1 of a task, and rt_bin_shadow for
+// the start points of a whole world cell).  The ray's start is tied to its direction — start = X + eps dir,
+// X = light - dir (kernels.cl:323-324) — so
+//   b = start - v0 = L - (1 - eps) dir + Delta,   L = light - v0,  |Delta| = a few ulps of the coordinates,
+// and with d = dir + j (j the jitter), det(dir, dir, e) = 0:
+//   det(A)  = -d.c                                  det(A0) = L.c - (1 - eps) dir.c + Delta.c
+//   det(A1) = -dir.cof(L,e2) - j.cof(b,e2) + ...    det(A2) = -dir.cof(e1,L) - j.cof(e1,b) + ...
+// i.e. linear in the direction alone, with coefficients fixed per frame, plus a jitter term.  task_bound
+// must treat the start box and the direction box of an arbitrary point set as independent, which doubles
+// the width; here the direction box (D0 +- ed) counts once, and the start box (s0 +- es) only scales the
+// jitter term.   M : bound on the coordinates involved (|light|, |v0|, |dir|), for the rounding terms.
+__device__ __forceinline__ Bound light_bundle_bound(const TriLane& T, f3 light, f3 s0, float es, f3 D0, float ed, float hh,
+                                                    float dlen_min, float dlen_max, float M) {
+  const f3 Lv = light - T.v0;
+  const float Linf = fmaxf(fmaxf(fabsf(Lv.x), fabsf(Lv.y)), fabsf(Lv.z));
+  const f3 pL = cof(Lv, T.e2), qL = cof(T.e1, Lv);
+  const f3 b0 = s0 - T.v0;
+  const float binf = fmaxf(fmaxf(fabsf(b0.x), fabsf(b0.y)), fabsf(b0.z));
+  const float eb = 1.001f * es + 1e-6f * (binf + es);                // |b - b0| per component, any point
+  const float pj = norm1(cof(b0, T.e2)) + 2.002f * eb * T.e2_1;      // >= |cof(b,e2)|_1, any point
+  const float qj = norm1(cof(T.e1, b0)) + 2.002f * eb * T.e1_1;
+  const f3 md = -D0;
+  const float A0 = detc(md, T.c), N1 = detc(md, pL), N2 = detc(md, qL);
+  const float nA0 = detc(Lv, T.c) + 0.9999f * A0;                    // L.c - (1 - eps) D0.c
+  const float ed1 = 1.001f * ed;                                     // |dir - D0| per component, any point
+  const float Bmax = Linf + dlen_max;                                // |b| per component
+  const float rnd = 8e-6f * dlen_max * (Bmax + M);                   // roundings of cof(b,e), of the dots, Delta
+  const float E0 = (ed1 + 4e-6f * (M + Bmax)) * T.c1 * 1.0001f;
+  const float EA = (ed1 + hh) * T.c1 * 1.0001f;
+  const float E1 = (ed1 * norm1(pL) + hh * pj + rnd * T.e2_1) * 1.0001f;
+  const float E2 = (ed1 * norm1(qL) + hh * qj + rnd * T.e1_1) * 1.0001f;
+  const float aD = fabsf(A0), hiD = aD + EA, loD = aD - EA;
+  const bool robust = aD > EA + 1e-30f;
+  const float sg = copysignf(1.0f, A0);
+  const float tn = sg * nA0, un = sg * N1, vn = sg * N2;
+  const float dmin = fmaxf(dlen_min - 1.7321f * hh, 0.0f), dmax = dlen_max + 1.7321f * hh;
+  const bool can_pos = (A0 + EA > 0.0f) && (nA0 + E0 > -1e-18f) && (N1 + E1 > -1e-18f) && (N2 + E2 > -1e-18f);
+  const bool can_neg = (A0 - EA < 0.0f) && (nA0 - E0 < 1e-18f) && (N1 - E1 < 1e-18f) && (N2 - E2 < 1e-18f);
+  const bool cR = (fabsf(nA0) - E0) * dmin > hiD * (dlen_max * 1.000004f);   // |t d|^2 >= radius_sq everywhere
+  const bool cW = fabsf(N1 + N2) - (E1 + E2) > hiD * 1.000004f;              // u+v > 1 wherever u,v >= 0
+  Bound r;
+  r.clear = (!can_pos && !can_neg) || cR || cW;
+  r.all_blocked = robust && (tn - E0 > 1e-18f) && (un - E1 > 1e-18f) && (vn - E2 > 1e-18f) &&
+                  ((un + vn) + (E1 + E2) < loD * 0.999996f) &&
+                  ((fabsf(nA0) + E0) * dmax < loD * (dlen_min * 0.999996f));
+  return r;
+}
+
 // Level 2 (lane = surface point): the same question for ONE point (this lane's) and a wave-uniform
 // triangle.  hh >= h plus every rounding error of the per-sample evaluation; every sample's det(A) lies in
 // D0 +- hh*|c|_1, det(A1) in N1 +- hh*|p|_1, det(A2) in N2 +- hh*|q|_1 (they are linear in the direction).

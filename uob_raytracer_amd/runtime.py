@@ -150,6 +150,7 @@ class RayTracer:
         _check(lib().rt_init(C.byref(cfg), _fp(v), _fp(nr), _fp(c), len(scene), C.byref(h)))
         self._h = h
         self.width = cfg.width
+        self.n_triangles = len(scene)
         self.rows = lib().rt_config_owned_rows(C.byref(cfg))
 
     def close(self):
@@ -197,8 +198,12 @@ class RayTracer:
         rot, cam, light = self._args(rot, cam, light)
         out = (C.c_uint64 * 8)()
         _check(lib().rt_count_executed(self._h, _fp(rot), _fp(cam), _fp(light), C.c_float(focal), out))
-        keys = ("surface_points", "stage1_wave_iterations", "stage2_wave_iterations", "sphere_wave_evaluations",
-                "culled_pairs", "tasks_resolved_whole")
+        if self.n_triangles > 64:      # tiled mesh kernel
+            keys = ("primary_tile_visits", "primary_bound_survivors", "shadow_tile_visits", "level1_survivors",
+                    "level3_pair_calls", "level3_stage1_iterations", "shadow_visits_nothing_culled", "wave_task_rounds")
+        else:
+            keys = ("surface_points", "stage1_wave_iterations", "stage2_wave_iterations", "sphere_wave_evaluations",
+                    "culled_pairs", "tasks_resolved_whole")
         return {k: int(out[i]) for i, k in enumerate(keys)}
 
     def last_kernel_ms(self):
