@@ -26,11 +26,13 @@ namespace uobrt {
 namespace {
 
 constexpr int kTile = 64;                   // triangles per LDS tile
+constexpr int kBatch = 4;                   // candidate tiles staged per barrier round (4 records of each: 16 KB)
+constexpr int kSlot = 4 * kTile;            // float4 per staged tile
 constexpr int kMeshWaves = 4;               // waves (= tasks) per workgroup sharing a tile
 constexpr int kDirectSamples = 2;           // up to this many, level 2 is skipped as well (the test is cheaper than its bound)
 constexpr int kPointSamples = 8;            // up to this many shadow samples, level 3 runs lane = surface point
-constexpr int kScreenCell = 64;             // pixels per side of a screen cell of the primary-ray tile masks
-constexpr int kScreenCellLog = 6;
+constexpr int kScreenCell = 32;             // pixels per side of a screen cell of the primary-ray tile masks
+constexpr int kScreenCellLog = 5;
 
 __device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
   return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
@@ -50,8 +52,10 @@ struct MeshWaveLds {
   float4* h0;   // start.xyz | radius_sq
   float4* h1;   // dir.xyz
   uint32_t* rng;
+  float4* grp;  // 4 float4 per group: s0|es, D0|ed, (dlen_min, dlen_max, hh, M), (lane mask lo, hi, -, -)
 };
-constexpr int kMeshWaveLdsBytes = 64 * 32 + kRngPixels * kRngStride * 4;
+constexpr int kMaxGroups = 6;               // coherent groups of a task's surface points bounded separately by level 1
+constexpr int kMeshWaveLdsBytes = 64 * 32 + kRngPixels * kRngStride * 4 + kMaxGroups * 64;
 
 __device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int lane) {
   return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(v >> 32), lane) << 32) |
@@ -70,11 +74,10 @@ __device__ __forceinline__ Mask2 tile_test_pair(const float4* tv0, const float4*
   const float ra = ha0.w, rb = hb0.w;
   const f3 da = mk(ha1.x, ha1.y, ha1.z) + jit, db = mk(hb1.x, hb1.y, hb1.z) + jit;   // dir + crush(...), :333
   const f3 nda = -da, ndb = -db;
-  int pos = 0;
-  for (unsigned long long kk = K; kk != 0ull; kk &= kk - 1ull, ++pos) {
-    if (((need >> pos) & 1ull) == 0ull) continue;
-    ++iters;
+  for (unsigned long long kk = K; kk != 0ull; kk &= kk - 1ull) {
     const int k = __builtin_ctzll(kk);
+    if (((need >> k) & 1ull) == 0ull) continue;
+    ++iters;
     const f3 v0 = xyz(tv0[k]), e1 = xyz(te1[k]), e2 = xyz(te2[k]), c = xyz(tc[k]);
     const f3 ba = sa - v0, bb = sb - v0;
     const float nA0a = detc(ba, c), nA0b = detc(bb, c);
@@ -251,16 +254,18 @@ __global__ __launch_bounds__(64 * kMeshWaves) void rt_draw_mesh(const FrameParam
   unsigned long long xw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tlast = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
   extern __shared__ float4 lds[];
-  float4* tile = lds;                                   // 8 records x kTile triangles
+  float4* tile = lds;                                   // kBatch staged tiles x 4 records x kTile triangles
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
-  const MeshWaveLds L{reinterpret_cast<float4*>(reinterpret_cast<char*>(lds + 8 * kTile) + wave * kMeshWaveLdsBytes),
-                      reinterpret_cast<float4*>(reinterpret_cast<char*>(lds + 8 * kTile) + wave * kMeshWaveLdsBytes + 64 * 16),
-                      reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(lds + 8 * kTile) + wave * kMeshWaveLdsBytes + 64 * 32)};
+  const MeshWaveLds L{reinterpret_cast<float4*>(reinterpret_cast<char*>(lds + kBatch * kSlot) + wave * kMeshWaveLdsBytes),
+                      reinterpret_cast<float4*>(reinterpret_cast<char*>(lds + kBatch * kSlot) + wave * kMeshWaveLdsBytes + 64 * 16),
+                      reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(lds + kBatch * kSlot) + wave * kMeshWaveLdsBytes + 64 * 32),
+                      reinterpret_cast<float4*>(reinterpret_cast<char*>(lds + kBatch * kSlot) + wave * kMeshWaveLdsBytes + 64 * 32 +
+                                                kRngPixels * kRngStride * 4)};
   const int n = P.n, ntiles = (n + kTile - 1) / kTile;
   const int nwords = (ntiles + 63) >> 6;
   // candidate-tile masks of this workgroup: primary rays (fixed for the frame), shadow rays (per task round)
-  unsigned long long* pmask = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(lds + 8 * kTile) +
+  unsigned long long* pmask = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(lds + kBatch * kSlot) +
                                                                     kMeshWaves * kMeshWaveLdsBytes);
   unsigned long long* smask = pmask + nwords;
   const bool bins = P.screen_masks != nullptr;
@@ -281,8 +286,6 @@ __global__ __launch_bounds__(64 * kMeshWaves) void rt_draw_mesh(const FrameParam
   }
   __syncthreads();
   const LdsScene G = lds_scene(P.records, n);           // the whole mesh, in HBM (hit finalisation, bounce rays)
-  const float4 *t_v0 = tile, *t_e1 = tile + kTile, *t_e2 = tile + 2 * kTile, *t_c = tile + 3 * kTile,
-               *t_col = tile + 5 * kTile, *t_pc = tile + 6 * kTile, *t_qc = tile + 7 * kTile;
 
   const int aa = P.aa_x * P.aa_y;                       // a power of two <= 64 (mesh_kernel_supports())
   const int la = __builtin_ctz(aa);
@@ -300,12 +303,26 @@ __global__ __launch_bounds__(64 * kMeshWaves) void rt_draw_mesh(const FrameParam
   const unsigned long long active = NS == 64 ? ~0ull : ((1ull << NS) - 1ull);
   Work wk;
 
-  // cooperative tile load: 8 records x 64 triangles = 512 float4, two per thread
-  auto load_tile = [&](int t) {
+  // Candidate tiles are staged kBatch at a time (one barrier round each): 4 records x 64 triangles per tile,
+  // one float4 per thread and tile.  primary: c|det(cam-v0,e1,e2), cof(cam-v0,e2), cof(e1,cam-v0);
+  // shadow: v0|material, e1, e2, c.
+  auto next_tile = [&](const unsigned long long* mask, int& w, unsigned long long& m) -> int {
+    while (m == 0ull) {
+      if (++w >= nwords) return -1;
+      m = uniform64(mask[w]);
+    }
+    const int t = w * 64 + __builtin_ctzll(m);
+    m &= m - 1ull;
+    return t < ntiles ? t : -1;
+  };
+  auto load_batch = [&](int t0, int t1, int t2, int t3, int cnt, bool primary) {
+    const int rec = tid >> 6, i = tid & 63;
+    const int src = primary ? (rec == 0 ? 3 : rec == 1 ? 6 : 7) : rec;
     __syncthreads();
-    for (int r = tid; r < 8 * kTile; r += 64 * kMeshWaves) {
-      const int rec = r >> 6, gi = t * kTile + (r & 63);
-      tile[r] = gi < n ? P.records[(size_t)rec * n + gi] : make_float4(0.f, 0.f, 0.f, -1.0f);
+    for (int sl = 0; sl < cnt; ++sl) {
+      const int t = sl == 0 ? t0 : sl == 1 ? t1 : sl == 2 ? t2 : t3;
+      const int gi = t * kTile + i;
+      tile[sl * kSlot + tid] = gi < n ? P.records[(size_t)src * n + gi] : make_float4(0.f, 0.f, 0.f, -1.0f);
     }
     __syncthreads();
   };
@@ -348,13 +365,8 @@ __global__ __launch_bounds__(64 * kMeshWaves) void rt_draw_mesh(const FrameParam
     float current_t = RT_MAXFLOAT, bu = 0.f, bv = 0.f;
     int best = -1;
     const f3 ndp = -ray.dir;
-    for (int w = 0; w < nwords; ++w)
-    for (unsigned long long tm = uniform64(pmask[w]); tm != 0ull; tm &= tm - 1ull) {
-      const int t = w * 64 + __builtin_ctzll(tm);
-      if (t >= ntiles) break;
-      MESH_STAMP(2)
-      load_tile(t);
-      MESH_STAMP(1)
+    auto primary_tile = [&](int t, const float4* tb) {
+      const float4 *t_c = tb, *t_pc = tb + kTile, *t_qc = tb + 2 * kTile;
       const int nc = (n - t * kTile) < kTile ? (n - t * kTile) : kTile;
       unsigned long long Kp = nc == 64 ? ~0ull : ((1ull << nc) - 1ull);
       {
@@ -375,6 +387,23 @@ __global__ __launch_bounds__(64 * kMeshWaves) void rt_draw_mesh(const FrameParam
             best = t * kTile + i; bu = u; bv = v; current_t = tt;
           }
         }
+      }
+    };
+    {
+      int bw = -1;
+      unsigned long long bm = 0ull;
+      for (;;) {
+        int t0 = -1, t1 = -1, t2 = -1, t3 = -1, cnt = 0;
+        if ((t0 = next_tile(pmask, bw, bm)) >= 0) { cnt = 1;
+          if ((t1 = next_tile(pmask, bw, bm)) >= 0) { cnt = 2;
+            if ((t2 = next_tile(pmask, bw, bm)) >= 0) { cnt = 3;
+              if ((t3 = next_tile(pmask, bw, bm)) >= 0) cnt = 4; } } }
+        if (cnt == 0) break;
+        MESH_STAMP(2)
+        load_batch(t0, t1, t2, t3, cnt, true);
+        MESH_STAMP(1)
+        for (int sl = 0; sl < cnt; ++sl) primary_tile(sl == 0 ? t0 : sl == 1 ? t1 : sl == 2 ? t2 : t3, tile + sl * kSlot);
+        if (cnt < kBatch) break;
       }
     }
     MESH_STAMP(2)
@@ -411,21 +440,38 @@ __global__ __launch_bounds__(64 * kMeshWaves) void rt_draw_mesh(const FrameParam
     if (!sane || !(dminlen > 0.0f)) dminlen = 0.0f;
     const float dk = dlen * 1.000004f;
     const unsigned long long sphmask = ballot(lit && P.nsph > 0 && spheres_maybe(P, start, dir, dlen, hh));
-    f3 s0 = mk(0.f, 0.f, 0.f), D0 = mk(0.f, 0.f, 0.f);
-    float es = 0.f, ed = 0.f, dlen_max = 0.f, dlen_min = 0.f, hh_task = 0.f, m_task = 0.f;
-    bool task_ok = false;
-    if (litmask != 0ull) {
-      const int jr = __builtin_ctzll(litmask);
-      s0 = mk(rl(start.x, jr), rl(start.y, jr), rl(start.z, jr));
-      D0 = mk(rl(dir.x, jr), rl(dir.y, jr), rl(dir.z, jr));
-      const f3 ds = start - s0, dd = dir - D0;
-      es = wave_max(lit ? fmaxf(fmaxf(fabsf(ds.x), fabsf(ds.y)), fabsf(ds.z)) : 0.0f);
-      ed = wave_max(lit ? fmaxf(fmaxf(fabsf(dd.x), fabsf(dd.y)), fabsf(dd.z)) : 0.0f);
-      dlen_max = wave_max(lit ? dlen : 0.0f);
-      dlen_min = wave_min(lit ? dlen : 3.0e38f);
-      task_ok = (ballot(lit && !sane) == 0ull) && es < 1e30f && ed < 1e30f;
-      hh_task = 1.002f * hbox + 2e-6f * (dlen_max + hbox);
-      m_task = fmaxf(fmaxf(fabsf(light.x), fabsf(light.y)), fabsf(light.z)) + dlen_max;
+    // Level 1 bounds a SET of surface points, and is only as tight as the set is compact.  A task whose pixels
+    // straddle a silhouette holds points on surfaces far apart, so the lit points are split into groups by
+    // world cell (the last group takes whatever is left) and each group is bounded on its own.
+    const bool task_ok = litmask != 0ull && ballot(lit && !sane) == 0ull;
+    int ngroups = 0, grp = -1;
+    if (task_ok) {
+      const int ci = bins ? world_cell(P, start) : 0;
+      const float linf_l = fmaxf(fmaxf(fabsf(light.x), fabsf(light.y)), fabsf(light.z));
+      for (unsigned long long rem = litmask; rem != 0ull; ++ngroups) {
+        const int jr = __builtin_ctzll(rem);
+        const int cj = __builtin_amdgcn_readlane(ci, jr);
+        const unsigned long long gm = ngroups == kMaxGroups - 1 ? rem : (rem & ballot(ci == cj));
+        rem &= ~gm;
+        const bool in = ((gm >> lane) & 1ull) != 0ull;
+        const f3 s0 = mk(rl(start.x, jr), rl(start.y, jr), rl(start.z, jr));
+        const f3 D0 = mk(rl(dir.x, jr), rl(dir.y, jr), rl(dir.z, jr));
+        const f3 ds = start - s0, dd = dir - D0;
+        const float es = wave_max(in ? fmaxf(fmaxf(fabsf(ds.x), fabsf(ds.y)), fabsf(ds.z)) : 0.0f);
+        const float ed = wave_max(in ? fmaxf(fmaxf(fabsf(dd.x), fabsf(dd.y)), fabsf(dd.z)) : 0.0f);
+        const float dlen_max = wave_max(in ? dlen : 0.0f);
+        const float dlen_min = wave_min(in ? dlen : 3.0e38f);
+        if (in) grp = ngroups;
+        if (lane == 0) {
+          L.grp[4 * ngroups] = make_float4(s0.x, s0.y, s0.z, es);
+          L.grp[4 * ngroups + 1] = make_float4(D0.x, D0.y, D0.z, ed);
+          L.grp[4 * ngroups + 2] = make_float4(dlen_min, dlen_max, 1.002f * hbox + 2e-6f * (dlen_max + hbox), linf_l + dlen_max);
+          L.grp[4 * ngroups + 3] = make_float4(__uint_as_float((unsigned)gm), __uint_as_float((unsigned)(gm >> 32)), 0.f, 0.f);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     // this lane's pixel's xorshift stream after the seed call (kernels.cl:319), for the point-parallel level 3
     uint32_t rs0 = 0u, rs1 = 0u, rs2 = 0u;
@@ -458,37 +504,53 @@ __global__ __launch_bounds__(64 * kMeshWaves) void rt_draw_mesh(const FrameParam
     }
     __syncthreads();
     MESH_STAMP(3)
-    for (int w = 0; w < nwords; ++w)
-    for (unsigned long long tm = uniform64(smask[w]); tm != 0ull; tm &= tm - 1ull) {
-      const int t = w * 64 + __builtin_ctzll(tm);
-      if (t >= ntiles) break;
-      MESH_STAMP(7)
-      load_tile(t);
-      MESH_STAMP(4)
-      if (litmask == 0ull || task_blocked) continue;            // wave-uniform; the barriers are behind us
+    auto shadow_tile = [&](int t, const float4* tbase) {
+      const float4 *t_v0 = tbase, *t_e1 = tbase + kTile, *t_e2 = tbase + 2 * kTile, *t_c = tbase + 3 * kTile;
+      if (litmask == 0ull || task_blocked) return;              // wave-uniform; the barriers are behind us
       const int nc = (n - t * kTile) < kTile ? (n - t * kTile) : kTile;
-      const unsigned long long casts = ballot(lane < nc && t_col[lane].w != -1.0f);    // glass casts no shadow, :247
+      const unsigned long long casts = ballot(lane < nc && t_v0[lane].w != -1.0f);    // glass casts no shadow, :247
       unsigned long long K = casts;
-      if (task_ok) {                                               // level 1, lane = triangle
+      unsigned long long mymask = casts;          // the tile triangles THIS lane's surface point may still need
+      if (task_ok) {                                               // level 1, lane = triangle, per group of points
         TriLane T1;
         T1.v0 = xyz(t_v0[lane]); T1.e1 = xyz(t_e1[lane]); T1.e2 = xyz(t_e2[lane]); T1.c = xyz(t_c[lane]);
         T1.c1 = norm1(T1.c); T1.e1_1 = norm1(T1.e1); T1.e2_1 = norm1(T1.e2);
-        const Bound tb = light_bundle_bound(T1, light, s0, es, D0, ed, hh_task, dlen_min, dlen_max, m_task + norm1(T1.v0));
-        K = casts & ~ballot(tb.clear);
-        if ((casts & ballot(tb.all_blocked)) != 0ull) { task_blocked = true; continue; }
+        const float v0n = norm1(T1.v0);
+        const unsigned long long alive = ballot(lit && !blocked && (my_sh & active) != active);
+        K = 0ull; mymask = 0ull;
+        for (int g = 0; g < ngroups; ++g) {
+          const float4 g0 = L.grp[4 * g], g1 = L.grp[4 * g + 1], g2 = L.grp[4 * g + 2], g3 = L.grp[4 * g + 3];
+          const unsigned long long gm = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(g3.y)) << 32) |
+                                        (unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(g3.x));
+          if ((gm & alive) == 0ull) continue;
+          unsigned long long Kg = casts;
+          if (g0.w < 1e30f && g1.w < 1e30f) {
+            const Bound tb = light_bundle_bound(T1, light, mk(g0.x, g0.y, g0.z), g0.w, mk(g1.x, g1.y, g1.z), g1.w, g2.z, g2.x, g2.y,
+                                                g2.w + v0n);
+            Kg = casts & ~ballot(tb.clear);
+            if ((casts & ballot(tb.all_blocked)) != 0ull) {          // one triangle blocks every sample of the group
+              if (grp == g) blocked = true;
+              continue;
+            }
+          }
+          if (grp == g) mymask = Kg;
+          K |= Kg;
+        }
+        if (ballot(lit && !blocked) == 0ull) { task_blocked = true; return; }
       }
       MESH_STAMP(5)
       if (COUNT) { xw[2]++; xw[3] += __popcll(K); xw[6] += (K == casts && __popcll(casts) > 32) ? 1 : 0; }
-      if (K == 0ull) continue;
-      unsigned long long need = 0ull;                              // level 2, lane = surface point
-      int pos = 0;
+      if (K == 0ull) return;
+      unsigned long long need = 0ull;                              // level 2, lane = surface point; bit = tile triangle
       // with one or two samples per point the bound costs more than the samples: test every candidate
-      if (NS <= kDirectSamples) need = ~0ull;
-      else for (unsigned long long kk = K; kk != 0ull; kk &= kk - 1ull, ++pos) {
+      if (NS <= kDirectSamples) need = mymask;
+      else for (unsigned long long kk = K; kk != 0ull; kk &= kk - 1ull) {
         const int kq = __builtin_ctzll(kk);
+        const bool part = ((mymask >> kq) & 1ull) != 0ull;
+        if (ballot(part && lit && !blocked) == 0ull) continue;
         const Bound pb = point_bound(start, dir, hh, dlen, dminlen, dk, xyz(t_v0[kq]), xyz(t_e1[kq]), xyz(t_e2[kq]), xyz(t_c[kq]));
-        if (!pb.clear || !sane) need |= 1ull << pos;
-        blocked = blocked || (sane && pb.all_blocked);
+        if (part && (!pb.clear || !sane)) need |= 1ull << kq;
+        blocked = blocked || (part && sane && pb.all_blocked);
       }
       MESH_STAMP(6)
       const bool mine = lit && !blocked && need != 0ull && (my_sh & active) != active;
@@ -506,12 +568,11 @@ __global__ __launch_bounds__(64 * kMeshWaves) void rt_draw_mesh(const FrameParam
             const f3 d = dir + mk(crush1(r0, P.spread), crush1(r1, P.spread), crush1(r2, P.spread));   // :333
             const f3 nd = -d;
             bool hit = false;
-            int pos2 = 0;
-            for (unsigned long long kk = K; kk != 0ull; kk &= kk - 1ull, ++pos2) {
-              const bool go = todo && !hit && ((need >> pos2) & 1ull) != 0ull;
+            for (unsigned long long kk = K; kk != 0ull; kk &= kk - 1ull) {
+              const int kq = __builtin_ctzll(kk);
+              const bool go = todo && !hit && ((need >> kq) & 1ull) != 0ull;
               if (ballot(go) == 0ull) continue;
               if (COUNT) xw[5]++;
-              const int kq = __builtin_ctzll(kk);
               if (go) {
                 const f3 v0 = xyz(t_v0[kq]), c = xyz(t_c[kq]);
                 const f3 b = start - v0;
@@ -531,7 +592,7 @@ __global__ __launch_bounds__(64 * kMeshWaves) void rt_draw_mesh(const FrameParam
           }
           if (COUNT) xw[4]++;
         }
-        continue;
+        return;
       }
       for (int g = 0; g * GL < 64 && work != 0ull; ++g) {          // level 3, lane = shadow sample
         const unsigned long long gm = (work >> (g * GL)) & (GL == 64 ? ~0ull : ((1ull << GL) - 1ull));
@@ -555,6 +616,23 @@ __global__ __launch_bounds__(64 * kMeshWaves) void rt_draw_mesh(const FrameParam
             if (lane == j) my_sh = m2.a;
           }
         }
+      }
+    };
+    {
+      int bw = -1;
+      unsigned long long bm = 0ull;
+      for (;;) {
+        int t0 = -1, t1 = -1, t2 = -1, t3 = -1, cnt = 0;
+        if ((t0 = next_tile(smask, bw, bm)) >= 0) { cnt = 1;
+          if ((t1 = next_tile(smask, bw, bm)) >= 0) { cnt = 2;
+            if ((t2 = next_tile(smask, bw, bm)) >= 0) { cnt = 3;
+              if ((t3 = next_tile(smask, bw, bm)) >= 0) cnt = 4; } } }
+        if (cnt == 0) break;
+        MESH_STAMP(7)
+        load_batch(t0, t1, t2, t3, cnt, false);
+        MESH_STAMP(4)
+        for (int sl = 0; sl < cnt; ++sl) shadow_tile(sl == 0 ? t0 : sl == 1 ? t1 : sl == 2 ? t2 : t3, tile + sl * kSlot);
+        if (cnt < kBatch) break;
       }
     }
     // shadow-casting spheres (kernels.cl:278-307) for the points whose rays can reach one
@@ -610,7 +688,8 @@ __global__ __launch_bounds__(64 * kMeshWaves) void rt_draw_mesh(const FrameParam
   if (PROF) { if (lane == 0) for (int q = 0; q < 8; ++q) atomicAdd(&P.counters[q], xw[q]); return; }
   if (COUNT) {
     xw[7] = aa;
-    if (lane == 0) for (int q = 0; q < 8; ++q) if (xw[q]) atomicAdd(&P.counters[q], xw[q]);
+    if (lane == 0) for (int q = 0; q < 8; ++q) if (xw[q] && q != 6) atomicAdd(&P.counters[q], xw[q]);
+    if (lane == 0) atomicMax(&P.counters[6], xw[3]);       // heaviest wave: level-1 survivors
   }
   const int x = B.x0 + (lane & 7);
   const int lr = B.lr0 + (lane >> 3);
@@ -643,7 +722,7 @@ void launch_mesh(const FrameParams& P, bool count, hipStream_t stream) {
     hipLaunchKernelGGL(rt_bin_shadow, dim3((ntiles + kMeshWaves - 1) / kMeshWaves, P.grid_g / 2), block, 0, stream, P);
   }
   const dim3 grid((P.W + 15) / 16, (P.owned_rows + 15) / 16);
-  const size_t lds_bytes = 8 * kTile * sizeof(float4) + kMeshWaves * (size_t)kMeshWaveLdsBytes + 2 * (size_t)nwords * 8;
+  const size_t lds_bytes = kBatch * kSlot * sizeof(float4) + kMeshWaves * (size_t)kMeshWaveLdsBytes + 2 * (size_t)nwords * 8;
   if (count && getenv("UOB_RT_PHASE_PROFILE")) hipLaunchKernelGGL((rt_draw_mesh<false, true>), grid, block, lds_bytes, stream, P);
   else if (count) hipLaunchKernelGGL((rt_draw_mesh<true>), grid, block, lds_bytes, stream, P);
   else hipLaunchKernelGGL((rt_draw_mesh<false>), grid, block, lds_bytes, stream, P);

@@ -8,7 +8,7 @@
 namespace uobrt {
 
 // LDS scene: float4 SoA records, one pass of staging per workgroup (stage_triangles).
-//   v0.xyz | e1.xyz | e2.xyz | c = cof(e1,e2).xyz , w = det(cam-v0, e1, e2)
+//   v0.xyz , w = colour.w | e1.xyz | e2.xyz | c = cof(e1,e2).xyz , w = det(cam-v0, e1, e2)
 //   normal | colour (w = material) | pc = cof(cam-v0, e2) | qc = cof(e1, cam-v0)
 // The last two (and c.w) are the camera-dependent terms of the PRIMARY-ray test: every primary ray
 // starts at the camera, so b = cam - v0 is the same for all of them (kernels.cl:106 with start = cam).
@@ -39,7 +39,7 @@ __device__ __forceinline__ void stage_triangles(const FrameParams& P, float4* ld
     const f3 cf = cof(e1, e2);
     const f3 bc = cam - v0;
     const f3 pc = cof(bc, e2), qc = cof(e1, bc);
-    lds[i] = make_float4(v0.x, v0.y, v0.z, 0.f);
+    lds[i] = make_float4(v0.x, v0.y, v0.z, P.colors[i].w);      // w: material flag (-1 = glass casts no shadow)
     lds[s + i] = make_float4(e1.x, e1.y, e1.z, 0.f);
     lds[2 * s + i] = make_float4(e2.x, e2.y, e2.z, 0.f);
     lds[3 * s + i] = make_float4(cf.x, cf.y, cf.z, detc(bc, cf));
