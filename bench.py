@@ -210,7 +210,11 @@ def main():
                         "per launch / kernel time. The kernel resolves most (surface point, triangle) pairs by an exact "
                         "interval bound instead of 64 per-sample tests, so the algorithmic rate can exceed the "
                         "hardware peak; `executed` is the arithmetic really issued."}
-    if total_exec:
+    if total_exec and "stage1_wave_iterations" not in total_exec:      # tiled mesh kernel (n > 64)
+        roofline["executed"] = dict({k: v for k, v in total_exec.items() if not k.startswith("_")},
+                                    note="work the tiled mesh kernel really executes (rt_count_executed): (wave, tile) "
+                                         "visits and the triangles its bounds leave, per pass")
+    elif total_exec:
         roofline["executed"] = {
             "sample_triangle_tests": 64 * total_exec["stage1_wave_iterations"],
             "fraction_of_reference_tests": 64 * total_exec["stage1_wave_iterations"] / max(total_work["shadow_tri_tests"], 1),
@@ -248,7 +252,7 @@ def main():
                          "note": "algorithmic bytes = 4 B/pixel ARGB + 80 B/triangle per workgroup; <<1% by construction"},
     }
 
-    if not collective and not args.no_brute_force and total_exec and args.workload == "headline":
+    if not collective and not args.no_brute_force and "stage1_wave_iterations" in total_exec and args.workload == "headline":
         # the same frame with the interval cull switched off (every triangle tested for every surface point)
         bcfg = abi.make_config(flags=abi.RT_FLAG_NO_CULL, device=local_rank, **wl)
         bt = rt.RayTracer(bcfg, scene)

@@ -25,6 +25,9 @@ namespace uobrt {
 
 namespace {
 
+#ifndef RT_MESH_MIN_BLOCKS
+#define RT_MESH_MIN_BLOCKS 4
+#endif
 constexpr int kTile = 64;                   // triangles per LDS tile
 constexpr int kBatch = 4;                   // candidate tiles staged per barrier round (4 records of each: 16 KB)
 constexpr int kSlot = 4 * kTile;            // float4 per staged tile
@@ -55,7 +58,9 @@ struct MeshWaveLds {
   float4* grp;  // 4 float4 per group: s0|es, D0|ed, (dlen_min, dlen_max, hh, M), (lane mask lo, hi, -, -)
 };
 constexpr int kMaxGroups = 6;               // coherent groups of a task's surface points bounded separately by level 1
-constexpr int kMeshWaveLdsBytes = 64 * 32 + kRngPixels * kRngStride * 4 + kMaxGroups * 64;
+__host__ __device__ constexpr int mesh_wave_lds_bytes(bool rng) {          // rng: scratch of the lane = sample level 3
+  return 64 * 32 + kMaxGroups * 64 + (rng ? kRngPixels * kRngStride * 4 : 0);
+}
 
 __device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int lane) {
   return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(v >> 32), lane) << 32) |
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(64 * kMeshWaves) void rt_bin_shadow(const FramePara
   const float linf = fmaxf(fmaxf(fabsf(light.x), fabsf(light.y)), fabsf(light.z));
   const float hbox = P.spread / 2.f;
   const float half = 0.5f * P.grid_cell;
-  const int G = P.grid_g, Gc = G >> 1, izc = blockIdx.y;            // grid.y = coarse z-slices (G is even)
+  const int G = P.grid_g;
   const float tv0inf = fmaxf(fmaxf(fabsf(T1.v0.x), fabsf(T1.v0.y)), fabsf(T1.v0.z));
   // every start point that world_cell() maps to the cell with centre C and half edge h lies in C +- hs
   // (slack: the rounding of that mapping); its dir = light - X (kernels.cl:323) = (light - C) + (C - X),
@@ -220,21 +225,25 @@ __global__ __launch_bounds__(64 * kMeshWaves) void rt_bin_shadow(const FramePara
     const float hh = 1.002f * hbox + 2e-6f * (dlen_max + hbox);
     return light_bundle_bound(T1, light, C, hs, D0, ed, hh, dlen_min, dlen_max, linf + tv0inf + dlen_max).clear;
   };
-  // two levels: a coarse cell of 2x2x2 cells first (what is clear for the union is clear for each of them)
-  for (int iyc = 0; iyc < Gc; ++iyc)
-    for (int ixc = 0; ixc < Gc; ++ixc) {
-      const f3 Cc = mk(P.grid_lo[0] + ((float)ixc + 0.5f) * (2.0f * P.grid_cell), P.grid_lo[1] + ((float)iyc + 0.5f) * (2.0f * P.grid_cell),
-                       P.grid_lo[2] + ((float)izc + 0.5f) * (2.0f * P.grid_cell));
-      if (ballot(ok && !cell_clear(Cc, 2.0f * half)) == 0ull) continue;
-      for (int sub = 0; sub < 8; ++sub) {
-        const int ix = 2 * ixc + (sub & 1), iy = 2 * iyc + ((sub >> 1) & 1), iz = 2 * izc + (sub >> 2);
-        const f3 C = mk(P.grid_lo[0] + ((float)ix + 0.5f) * P.grid_cell, P.grid_lo[1] + ((float)iy + 0.5f) * P.grid_cell,
-                        P.grid_lo[2] + ((float)iz + 0.5f) * P.grid_cell);
-        const unsigned long long m = ballot(ok && !cell_clear(C, half));
-        if (m != 0ull && lane == 0)
-          atomicOr(&P.world_masks[((size_t)(iz * G + iy) * G + ix) * P.nwords + (t >> 6)], 1ull << (t & 63));
+  // three levels, 4x4x4 -> 2x2x2 -> single cells: what is clear for a union of cells is clear for each of them
+  // (grid.y, grid.z = y, z of the coarsest level; G is a multiple of 4)
+  auto centre = [&](int ix, int iy, int iz, float edge) {
+    return mk(P.grid_lo[0] + ((float)ix + 0.5f) * edge, P.grid_lo[1] + ((float)iy + 0.5f) * edge, P.grid_lo[2] + ((float)iz + 0.5f) * edge);
+  };
+  const int Gq = G >> 2, izq = blockIdx.z, iyq = blockIdx.y;         // one row of coarsest cells per wave
+  for (int ixq = 0; ixq < Gq; ++ixq) {
+      if (ballot(ok && !cell_clear(centre(ixq, iyq, izq, 4.0f * P.grid_cell), 4.0f * half)) == 0ull) continue;
+      for (int s2 = 0; s2 < 8; ++s2) {
+        const int ixc = 2 * ixq + (s2 & 1), iyc = 2 * iyq + ((s2 >> 1) & 1), izc = 2 * izq + (s2 >> 2);
+        if (ballot(ok && !cell_clear(centre(ixc, iyc, izc, 2.0f * P.grid_cell), 2.0f * half)) == 0ull) continue;
+        for (int sub = 0; sub < 8; ++sub) {
+          const int ix = 2 * ixc + (sub & 1), iy = 2 * iyc + ((sub >> 1) & 1), iz = 2 * izc + (sub >> 2);
+          const unsigned long long m = ballot(ok && !cell_clear(centre(ix, iy, iz, P.grid_cell), half));
+          if (m != 0ull && lane == 0)
+            atomicOr(&P.world_masks[((size_t)(iz * G + iy) * G + ix) * P.nwords + (t >> 6)], 1ull << (t & 63));
+        }
       }
-    }
+  }
 }
 
 // Grid: x = ceil(W/16), y = ceil(owned_rows/16); block = 4 waves = 2x2 blocks of 8x8 pixels.
@@ -250,23 +259,22 @@ __global__ __launch_bounds__(64 * kMeshWaves) void rt_bin_shadow(const FramePara
     tlast = now_;                                                                   \
   }
 template <bool COUNT, bool PROF = false>
-__global__ __launch_bounds__(64 * kMeshWaves) void rt_draw_mesh(const FrameParams P) {
+__global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_mesh(const FrameParams P) {
   unsigned long long xw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tlast = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
   extern __shared__ float4 lds[];
   float4* tile = lds;                                   // kBatch staged tiles x 4 records x kTile triangles
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
-  const MeshWaveLds L{reinterpret_cast<float4*>(reinterpret_cast<char*>(lds + kBatch * kSlot) + wave * kMeshWaveLdsBytes),
-                      reinterpret_cast<float4*>(reinterpret_cast<char*>(lds + kBatch * kSlot) + wave * kMeshWaveLdsBytes + 64 * 16),
-                      reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(lds + kBatch * kSlot) + wave * kMeshWaveLdsBytes + 64 * 32),
-                      reinterpret_cast<float4*>(reinterpret_cast<char*>(lds + kBatch * kSlot) + wave * kMeshWaveLdsBytes + 64 * 32 +
-                                                kRngPixels * kRngStride * 4)};
+  const int wave_bytes = mesh_wave_lds_bytes(P.S > kPointSamples || P.nsph > 0);
+  char* const wbase = reinterpret_cast<char*>(lds + kBatch * kSlot) + wave * wave_bytes;
+  const MeshWaveLds L{reinterpret_cast<float4*>(wbase), reinterpret_cast<float4*>(wbase + 64 * 16),
+                      reinterpret_cast<uint32_t*>(wbase + 64 * 32 + kMaxGroups * 64), reinterpret_cast<float4*>(wbase + 64 * 32)};
   const int n = P.n, ntiles = (n + kTile - 1) / kTile;
   const int nwords = (ntiles + 63) >> 6;
   // candidate-tile masks of this workgroup: primary rays (fixed for the frame), shadow rays (per task round)
   unsigned long long* pmask = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(lds + kBatch * kSlot) +
-                                                                    kMeshWaves * kMeshWaveLdsBytes);
+                                                                    kMeshWaves * wave_bytes);
   unsigned long long* smask = pmask + nwords;
   const bool bins = P.screen_masks != nullptr;
   for (int w = tid; w < nwords; w += 64 * kMeshWaves) {
@@ -719,10 +727,10 @@ void launch_mesh(const FrameParams& P, bool count, hipStream_t stream) {
     hipMemsetAsync(P.screen_masks, 0, (size_t)P.scx * P.scy * nwords * 8, stream);
     hipMemsetAsync(P.world_masks, 0, (size_t)P.grid_g * P.grid_g * P.grid_g * nwords * 8, stream);
     hipLaunchKernelGGL(rt_bin_primary, dim3((ntiles + kMeshWaves - 1) / kMeshWaves, P.scy), block, 0, stream, P);
-    hipLaunchKernelGGL(rt_bin_shadow, dim3((ntiles + kMeshWaves - 1) / kMeshWaves, P.grid_g / 2), block, 0, stream, P);
+    hipLaunchKernelGGL(rt_bin_shadow, dim3((ntiles + kMeshWaves - 1) / kMeshWaves, P.grid_g / 4, P.grid_g / 4), block, 0, stream, P);
   }
   const dim3 grid((P.W + 15) / 16, (P.owned_rows + 15) / 16);
-  const size_t lds_bytes = kBatch * kSlot * sizeof(float4) + kMeshWaves * (size_t)kMeshWaveLdsBytes + 2 * (size_t)nwords * 8;
+  const size_t lds_bytes = kBatch * kSlot * sizeof(float4) + kMeshWaves * (size_t)mesh_wave_lds_bytes(P.S > kPointSamples || P.nsph > 0) + 2 * (size_t)nwords * 8;
   if (count && getenv("UOB_RT_PHASE_PROFILE")) hipLaunchKernelGGL((rt_draw_mesh<false, true>), grid, block, lds_bytes, stream, P);
   else if (count) hipLaunchKernelGGL((rt_draw_mesh<true>), grid, block, lds_bytes, stream, P);
   else hipLaunchKernelGGL((rt_draw_mesh<false>), grid, block, lds_bytes, stream, P);
