@@ -199,12 +199,22 @@ def main():
     # per launch = per rank: every rank runs the same kernel on 1/world of the frame
     flops_per_launch = flops / world
     achieved_tflops = flops_per_launch / (kernel_ms * 1e-3) / 1e12
-    wg = ((W + 63) // 64) * ((H // world + 3) // 4)
-    hbm_bytes_per_launch = W * (H // world) * 4 + wg * len(scene) * 80
+    # algorithmic HBM bytes per launch: the rank's share of the ARGB frame + the scene once (workgroups re-read it from L2)
+    hbm_bytes_per_launch = W * (H // world) * 4 + len(scene) * 80
     achieved_gbps = hbm_bytes_per_launch / (kernel_ms * 1e-3) / 1e9
 
+    # HBM bytes per launch from the PMC passes of this command, committed under profiles/ (counters cannot be
+    # collected from inside the run); only quoted for the workload and GPU count they were measured on
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            t = json.load(f).get(args.workload)
+        if t and t.get("n_gpus") == world:
+            traffic = t["bytes_per_launch"]
+    except (OSError, ValueError):
+        pass
     roofline = {"bound": "valu", "achieved": achieved_tflops, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved_tflops / PEAK_FP32_VALU_TFLOPS, "traffic": None,
+                "frac": achieved_tflops / PEAK_FP32_VALU_TFLOPS, "traffic": traffic,
                 "note": "FP32 vector-ALU roof (SURVEY.md 8d; this path is neither HBM- nor MFMA-bound). achieved = "
                         "ALGORITHMIC flop: (triangle tests*46 + sphere tests*30) of the reference's brute-force loops "
                         "per launch / kernel time. The kernel resolves most (surface point, triangle) pairs by an exact "
@@ -248,8 +258,10 @@ def main():
         "parity": "bit-exact vs CPU oracle (strict FP32, reference operation order); tolerance allowed 1e-4",
         "roofline": roofline,
         "roofline_hbm": {"bound": "hbm", "achieved": achieved_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                         "frac": achieved_gbps / PEAK_HBM_GBPS, "traffic": None,
-                         "note": "algorithmic bytes = 4 B/pixel ARGB + 80 B/triangle per workgroup; <<1% by construction"},
+                         "frac": achieved_gbps / PEAK_HBM_GBPS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": hbm_bytes_per_launch,
+                         "note": "algorithmic bytes = 4 B/pixel ARGB + 80 B/triangle once; <<1% by construction; "
+                                 "traffic = HBM bytes per launch from the PMC passes in profiles/r01_pmc_traffic.json"},
     }
 
     if not collective and not args.no_brute_force and "stage1_wave_iterations" in total_exec and args.workload == "headline":
