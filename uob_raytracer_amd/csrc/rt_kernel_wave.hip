@@ -397,6 +397,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
         if (COUNT) xw.v[5] += 1;
       } else {
         // level 2: per surface point, lnB = point, over the triangles K that survived level 1
+
         bool blocked = false;
         need = 0ull;
         int pos = 0;
@@ -466,6 +467,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
 
     const int lnD = opaque(lane);
     // ---- phase 4: shade lnD-parallel (direct_light's sum :335, then :354 / :421-422) ----------------
+    if (COUNT) {      // outcome of the sampled points: fully lit / fully blocked after all (the rest is true penumbra)
+      xw.v[6] += (unsigned)__popcll(work & ballot(lit && unshadowed == NS));
+      xw.v[7] += (unsigned)__popcll(work & ballot(lit && unshadowed == 0));
+    }
     f3 contrib = mk(0.f, 0.f, 0.f);
     {
       // direct_light's running sum (:335): the same term added once per unblocked sample, in sequence.
@@ -514,7 +519,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
     return;
   }
   if (COUNT) {                               // wave-uniform counters: lane 0 publishes them
-    if (lane == 0) for (int q = 0; q < 6; ++q) if (xw.v[q]) atomicAdd(&P.counters[q], xw.v[q]);
+    if (lane == 0) for (int q = 0; q < 8; ++q) if (xw.v[q]) atomicAdd(&P.counters[q], xw.v[q]);
   }
 }
 

@@ -147,21 +147,32 @@ __device__ __forceinline__ Bound point_bound(f3 start, f3 dir, float hh, float d
   const f3 md = -dir;
   const float D0 = detc(md, c), N1 = detc(md, p), N2 = detc(md, q);
   const float aD = fabsf(D0);
-  const float Delta = hh * norm1(c);
+  const float c1 = norm1(c), p1 = norm1(p), q1 = norm1(q);
+  const float Delta = hh * c1;
   const bool robust = aD > Delta + 1e-30f;           // every sample's det(A) has D0's sign and is normal
   const float sg = copysignf(1.0f, D0);
   const float tn = sg * nA0, un = sg * N1, vn = sg * N2;
-  const float hp = hh * norm1(p), hq = hh * norm1(q);
+  const float hp = hh * p1, hq = hh * q1;
   const float hiD = aD + Delta, loD = aD - Delta;
+  // The third edge, exactly: det(A1) + det(A2) - det(A) = det(-d, b - e1, e2 - e1) is ONE linear function of
+  // the sample direction, so its range over the jitter box is centre +- hh |w|_1.  (Bounding the three
+  // determinants separately, as cW below must when det(A) may change sign, ignores that they move together:
+  // a ray skimming along a face passes its top edge at u+v = 1.03 for every sample, yet the three separate
+  // intervals overlap.)  slack: w is not formed the way the reference forms p, q and c, and the reference
+  // rounds u, v and u+v; both are a few 2^-24 of |d| (|p|+|q|+|c|).
+  const f3 w = cof(b - e1, e2 - e1);
+  const float W0 = sg * detc(md, w), hw = hh * norm1(w);
+  const float slackW = 4e-6f * (dlen + hh) * (p1 + q1 + c1);
   // sign consistency of det(A), det(A0), det(A1), det(A2) (see task_bound); det(A0) is exact here
   const bool can_pos = (D0 + Delta > 0.0f) && (nA0 > -1e-18f) && (N1 + hp > -1e-18f) && (N2 + hq > -1e-18f);
   const bool can_neg = (D0 - Delta < 0.0f) && (nA0 < 1e-18f) && (N1 - hp < 1e-18f) && (N2 - hq < 1e-18f);
   const bool cR = fabsf(nA0) * dminlen > hiD * dk;               // |t*d|^2 >= radius_sq for every sample
   const bool cW = fabsf(N1 + N2) - (hp + hq) > hiD * 1.000004f;  // u+v > 1 wherever u,v >= 0
+  const bool cE = robust && (W0 - hw > slackW);                  // u+v > 1 for every sample
   Bound r;
-  r.clear = (!can_pos && !can_neg) || cR || cW;
+  r.clear = (!can_pos && !can_neg) || cR || cW || cE;
   r.all_blocked = robust && (tn > 1e-18f) && (un - hp > 1e-18f) && (vn - hq > 1e-18f) &&
-                  ((un + vn) + (hp + hq) < loD * 0.999996f) &&
+                  (W0 + hw < -slackW) &&
                   (fabsf(nA0) * (dlen + 1.7321f * hh) < loD * (dlen * 0.999996f));
   return r;
 }

@@ -203,7 +203,7 @@ class RayTracer:
                     "level3_pair_calls", "level3_stage1_iterations", "shadow_visits_nothing_culled", "wave_task_rounds")
         else:
             keys = ("surface_points", "stage1_wave_iterations", "stage2_wave_iterations", "sphere_wave_evaluations",
-                    "culled_pairs", "tasks_resolved_whole")
+                    "culled_pairs", "tasks_resolved_whole", "sampled_points_fully_lit", "sampled_points_fully_blocked")
         return {k: int(out[i]) for i, k in enumerate(keys)}
 
     def last_kernel_ms(self):
