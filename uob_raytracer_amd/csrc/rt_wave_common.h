@@ -73,6 +73,13 @@ __device__ __forceinline__ Bound task_bound(const TriLane& T, f3 s0, f3 D0, floa
   const float sg = copysignf(1.0f, A0);
   const float tn = sg * nA0, un = sg * N1, vn = sg * N2;
   const float dmin = fmaxf(dlen_min - 1.7321f * hh, 0.0f), dmax = dlen_max + 1.7321f * hh;
+  // the third edge as ONE linear function of the direction (see point_bound): det(-d, b - e1, e2 - e1)
+  const f3 g = T.e2 - T.e1;
+  const f3 w0 = cof(b0 - T.e1, g);
+  const float w1 = norm1(w0), ew1 = 2.002f * eb * norm1(g);
+  const float W0 = sg * detc(md, w0);
+  const float EW = (dlen_max * ew1 + edd * (w1 + ew1)) * 1.0001f;
+  const float slackW = 4e-6f * (dlen_max + hh) * ((p1 + ep1) + (q1 + eq1) + T.c1);
   // A sample can only hit if det(A), det(A0), det(A1), det(A2) share one sign (t,u,v >= 0): cull when
   // neither the all-positive nor the all-negative combination is possible.  No condition on det(A): this
   // also settles rays that are nearly parallel to the triangle's plane, where det(A) changes sign.
@@ -80,10 +87,11 @@ __device__ __forceinline__ Bound task_bound(const TriLane& T, f3 s0, f3 D0, floa
   const bool can_neg = (A0 - EA < 0.0f) && (nA0 - E0 < 1e-18f) && (N1 - E1 < 1e-18f) && (N2 - E2 < 1e-18f);
   const bool cR = (fabsf(nA0) - E0) * dmin > hiD * (dlen_max * 1.000004f);   // |t d|^2 >= radius_sq everywhere
   const bool cW = fabsf(N1 + N2) - (E1 + E2) > hiD * 1.000004f;              // u+v > 1 wherever u,v >= 0
+  const bool cE = robust && (W0 - EW > slackW);                              // u+v > 1 for every sample
   Bound r;
-  r.clear = (!can_pos && !can_neg) || cR || cW;
+  r.clear = (!can_pos && !can_neg) || cR || cW || cE;
   r.all_blocked = robust && (tn - E0 > 1e-18f) && (un - E1 > 1e-18f) && (vn - E2 > 1e-18f) &&
-                  ((un + vn) + (E1 + E2) < loD * 0.999996f) &&
+                  (W0 + EW < -slackW) &&
                   ((fabsf(nA0) + E0) * dmax < loD * (dlen_min * 0.999996f));
   return r;
 }
@@ -124,14 +132,24 @@ __device__ __forceinline__ Bound light_bundle_bound(const TriLane& T, f3 light, 
   const float sg = copysignf(1.0f, A0);
   const float tn = sg * nA0, un = sg * N1, vn = sg * N2;
   const float dmin = fmaxf(dlen_min - 1.7321f * hh, 0.0f), dmax = dlen_max + 1.7321f * hh;
+  // the third edge as one linear function (see point_bound): det(A1)+det(A2)-det(A) = -dir.wL - j.wb,
+  // wL = cof(L - e1, e2 - e1), wb = cof(b - e1, e2 - e1)
+  const f3 g = T.e2 - T.e1;
+  const float g1 = norm1(g);
+  const f3 wL = cof(Lv - T.e1, g);
+  const float wj = norm1(cof(b0 - T.e1, g)) + 2.002f * eb * g1;      // >= |wb|_1, any point
+  const float W0 = sg * detc(md, wL);
+  const float EW = (ed1 * norm1(wL) + hh * wj + rnd * g1) * 1.0001f;
+  const float slackW = 4e-6f * (dlen_max + hh) * (pj + qj + T.c1);
   const bool can_pos = (A0 + EA > 0.0f) && (nA0 + E0 > -1e-18f) && (N1 + E1 > -1e-18f) && (N2 + E2 > -1e-18f);
   const bool can_neg = (A0 - EA < 0.0f) && (nA0 - E0 < 1e-18f) && (N1 - E1 < 1e-18f) && (N2 - E2 < 1e-18f);
   const bool cR = (fabsf(nA0) - E0) * dmin > hiD * (dlen_max * 1.000004f);   // |t d|^2 >= radius_sq everywhere
   const bool cW = fabsf(N1 + N2) - (E1 + E2) > hiD * 1.000004f;              // u+v > 1 wherever u,v >= 0
+  const bool cE = robust && (W0 - EW > slackW);                              // u+v > 1 for every sample
   Bound r;
-  r.clear = (!can_pos && !can_neg) || cR || cW;
+  r.clear = (!can_pos && !can_neg) || cR || cW || cE;
   r.all_blocked = robust && (tn - E0 > 1e-18f) && (un - E1 > 1e-18f) && (vn - E2 > 1e-18f) &&
-                  ((un + vn) + (E1 + E2) < loD * 0.999996f) &&
+                  (W0 + EW < -slackW) &&
                   ((fabsf(nA0) + E0) * dmax < loD * (dlen_min * 0.999996f));
   return r;
 }
@@ -193,7 +211,14 @@ __device__ __forceinline__ bool primary_clear(f3 duc, f3 eu, float dumax, f3 c, 
   const bool can_pos = (Ac + EA > 0.0f) && (nA0cam > -1e-18f) && (N1 + E1 > -1e-30f) && (N2 + E2 > -1e-30f);
   const bool can_neg = (Ac - EA < 0.0f) && (nA0cam < 1e-18f) && (N1 - E1 < 1e-30f) && (N2 - E2 < 1e-30f);
   const bool cW = fabsf(N1 + N2) - (E1 + E2) > (fabsf(Ac) + EA) * 1.000004f;
-  return (!can_pos && !can_neg) || cW;
+  // the third edge as one linear function of the direction (see point_bound); w = pc + qc - c is formed here
+  // from the staged cofactors, the rounding of that sum and of the reference's u, v, u+v goes into the slack
+  const f3 w = (pc + qc) - c;
+  const float cn = norm1(c) + norm1(pc) + norm1(qc);
+  const float W = copysignf(1.0f, Ac) * detc(md, w);
+  const float EW = eu.x * fabsf(w.x) + eu.y * fabsf(w.y) + eu.z * fabsf(w.z) + 2.0f * sl * cn;
+  const bool cE = (fabsf(Ac) > EA) && (W - EW > 0.0f);           // u+v > 1 for every ray of the bundle
+  return (!can_pos && !can_neg) || cW || cE;
 }
 
 // Can any ray of a bundle — origin `o`, directions dir + e with |e|_2 <= jm — touch a sphere?  Conservative:
