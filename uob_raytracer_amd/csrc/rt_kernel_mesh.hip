@@ -447,7 +447,10 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
     const bool sane = lit && (radius_sq > 1e-18f) && (radius_sq < 1e30f);
     if (!sane || !(dminlen > 0.0f)) dminlen = 0.0f;
     const float dk = dlen * 1.000004f;
-    const unsigned long long sphmask = ballot(lit && P.nsph > 0 && spheres_maybe(P, start, dir, dlen, hh));
+    SphereBound sb;
+    sb.maybe = false; sb.all_blocked = false;
+    if (P.nsph > 0 && sane) sb = spheres_point(P, start, dir, dlen, hh);
+    const unsigned long long sphmask = ballot(lit && P.nsph > 0 && (sb.maybe || !sane));
     // Level 1 bounds a SET of surface points, and is only as tight as the set is compact.  A task whose pixels
     // straddle a silhouette holds points on surfaces far apart, so the lit points are split into groups by
     // world cell (the last group takes whatever is left) and each group is bounded on its own.
@@ -488,7 +491,7 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
       rs0 = xorshift((uint32_t)gid); rs1 = xorshift((uint32_t)((float)gid * 91.0f)); rs2 = xorshift((uint32_t)((float)gid * 19.0f));
     }
     unsigned long long my_sh = 0ull;            // blocked samples of THIS lane's surface point, across tiles
-    bool blocked = false, task_blocked = false;
+    bool blocked = sane && sb.all_blocked, task_blocked = false;
     int rng_group = -1;                         // which pixel group's streams the scratch currently holds
     // candidate tiles of the workgroup's four tasks: OR of the world-cell masks of their lit surface points
     __syncthreads();

@@ -368,7 +368,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
       const bool sane = lit && (radius_sq > 1e-18f) && (radius_sq < 1e30f);
       if (!sane || !(dminlen > 0.0f)) dminlen = 0.0f;                  // disables the distance rule
       const float dk = dlen * 1.000004f;
-      sphmask = ballot(lit && P.nsph > 0 && spheres_maybe(P, start, dir, dlen, hh));
+      SphereBound sb;
+      sb.maybe = false; sb.all_blocked = false;
+      if (P.nsph > 0 && sane) sb = spheres_point(P, start, dir, dlen, hh);
+      sphmask = ballot(lit && P.nsph > 0 && (sb.maybe || !sane));
+      const bool sph_blocked = sane && sb.all_blocked;
       // level 1: all lit points of the task at once, lnB = triangle
       bool task_blocked = false;
       {
@@ -398,7 +402,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
       } else {
         // level 2: per surface point, lnB = point, over the triangles K that survived level 1
 
-        bool blocked = false;
+        bool blocked = sph_blocked;
         need = 0ull;
         int pos = 0;
         for (unsigned long long kk = K; kk != 0ull; kk &= kk - 1ull, ++pos) {

@@ -241,9 +241,37 @@ __device__ __forceinline__ bool sphere_bundle_maybe(const FrameParams& P, f3 o, 
   }
   return maybe;
 }
-// shadow rays of one surface point: jitter of half-width hh per axis
-__device__ __forceinline__ bool spheres_maybe(const FrameParams& P, f3 start, f3 dir, float dlen, float hh) {
-  return sphere_bundle_maybe(P, start, dir, dlen, 1.7321f * hh, true);
+// Shadow rays of ONE surface point against the shadow-casting spheres (kernels.cl:278-307): directions
+// dir + e, e in the box [-hh,hh]^3 (hh includes the rounding slack of the sample direction).
+//   returns maybe : some sample may touch a sphere (else the spheres need no evaluation for this point)
+//   all_blocked   : every sample provably hits one sphere before the light
+// With cr = L x dir and a = cr/|cr|:  |L x (dir+e)| >= (cr + L x e).a = |cr| + e.(a x L) >= |cr| - hh |a x L|_1
+// (the box's support function in the one direction that matters; a ball of radius sqrt(3) hh is up to 1.7x
+// wider).  Margins: 0.2 % / 1 % on the radius against the rounding of the reference's discriminant
+// b*b - 4*a*c (at most ~50*2^-24 |d|^2 (|L|^2 + R^2)): rigorous for |L|/R < 73, applied for |L|/R < 40;
+// farther or degenerate spheres are always evaluated.
+struct SphereBound { bool maybe, all_blocked; };
+__device__ __forceinline__ SphereBound spheres_point(const FrameParams& P, f3 start, f3 dir, float dlen, float hh) {
+  SphereBound r;
+  r.maybe = false; r.all_blocked = false;
+  const float jm = 1.7321f * hh;
+  for (int i = 0; i < P.nsph; ++i) {
+    const DevSphere& sp = P.sph[i];
+    if (sp.col[3] == -1.0f) continue;                               // glass casts no shadow, :279
+    const f3 Lv = start - mk(sp.cx, sp.cy, sp.cz);
+    const f3 cr = mk(Lv.y * dir.z - Lv.z * dir.y, Lv.z * dir.x - Lv.x * dir.z, Lv.x * dir.y - Lv.y * dir.x);
+    const f3 cl = mk(cr.y * Lv.z - cr.z * Lv.y, cr.z * Lv.x - cr.x * Lv.z, cr.x * Lv.y - cr.y * Lv.x);     // cr x L
+    const float crn = sqrtf(dot3(cr, cr)), Ln2 = dot3(Lv, Lv), Ln = sqrtf(Ln2), R = sqrtf(fmaxf(sp.r2, 0.0f));
+    const bool near = (Ln < 40.0f * R) && (sp.r2 > 0.0f);
+    const bool miss = near && (crn * crn - hh * norm1(cl) > R * (dlen + jm) * 1.002f * crn);
+    r.maybe = r.maybe || !miss;
+    // all samples: start outside the sphere, sphere ahead of the start and wholly nearer than the light
+    // (then both roots are positive and the near one lies within |L| of the start), line through the sphere
+    const bool hit = near && (Ln2 > 1.001f * sp.r2) && (dot3(dir, Lv) + hh * norm1(Lv) < 0.0f) && (Ln < 0.999f * dlen) &&
+                     (crn + Ln * jm < 0.99f * R * (dlen - jm)) && (dlen > jm);
+    r.all_blocked = r.all_blocked || hit;
+  }
+  return r;
 }
 
 }  // namespace
