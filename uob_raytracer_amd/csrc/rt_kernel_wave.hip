@@ -379,11 +379,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
         const int jr = __builtin_ctzll(work);
         const f3 s0 = mk(rl(start.x, jr), rl(start.y, jr), rl(start.z, jr));
         const f3 D0 = mk(rl(dir.x, jr), rl(dir.y, jr), rl(dir.z, jr));
-        const f3 ds = start - s0, dd = dir - D0;
-        const float es = wave_max(lit ? fmaxf(fmaxf(fabsf(ds.x), fabsf(ds.y)), fabsf(ds.z)) : 0.0f);
+        // One wave reduction instead of four: the points' start and dir move together (start = X + 1e-4 dir,
+        // dir = light - X, kernels.cl:323-324), so |start - s0| <= (1 + 1e-4) |dir - D0| + roundings of the
+        // coordinates, and |dir| lies within sqrt(3) ed of the reference point's.
+        const f3 dd = dir - D0;
         const float ed = wave_max(lit ? fmaxf(fmaxf(fabsf(dd.x), fabsf(dd.y)), fabsf(dd.z)) : 0.0f);
-        const float dlen_max = wave_max(lit ? dlen : 0.0f);
-        const float dlen_min = wave_min(lit ? dlen : 3.0e38f);
+        const float dlen0 = rl(dlen, jr);
+        const float dlen_max = (dlen0 + 1.7321f * ed) * 1.000001f;
+        const float dlen_min = fmaxf(dlen0 - 1.7321f * ed, 0.0f) * 0.999999f;
+        const float es = 1.0002f * ed + 2e-6f * (fmaxf(fmaxf(fabsf(light.x), fabsf(light.y)), fabsf(light.z)) + dlen_max);
         const bool all_sane = ballot(lit && !sane) == 0ull;
         if (all_sane && es < 1e30f && ed < 1e30f) {                    // finite, non-degenerate
           const float hh_task = 1.002f * hbox + 2e-6f * (dlen_max + hbox);
