@@ -309,6 +309,27 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
   const int x0 = (job - lr * P.nseg) * 64;
   const int y = band_global_row(lr, P.band_rows, P.band_index, P.band_count);
   f3 outc = mk(0.f, 0.f, 0.f);
+  // Triangles a primary ray of this job may hit, bounded once for the job's 64 x 1 pixels (all AA samples): the
+  // rays leave the camera through a sub-pixel rectangle, see primary_clear.  (Per task the rectangle is 8x
+  // narrower and a triangle or so fewer survives, but the bound itself costs more than that triangle's tests.)
+  unsigned long long Kp_job = n == 64 ? ~0ull : ((1ull << n) - 1ull);
+  if (CULL) {
+    const int lnJ = opaque(lane);
+    const float Xlo = (float)(x0 * P.aa_x) - ((float)P.W * (float)P.aa_x) / 2.0f;
+    const float Ylo = ((float)(y * P.aa_y) - ((float)P.H * (float)P.aa_y) / 2.0f) * P.sy;
+    const float hx = 0.5f * (float)(64 * P.aa_x - 1), hy = 0.5f * (float)(P.aa_y - 1) * P.sy;
+    const f3 wc = mk(Xlo + hx, Ylo + hy, P.focal);
+    const f3 r0 = mk(P.rot[0], P.rot[1], P.rot[2]), r1 = mk(P.rot[4], P.rot[5], P.rot[6]),
+             r2 = mk(P.rot[8], P.rot[9], P.rot[10]);
+    const f3 duc = mk(dot3(r0, wc), dot3(r1, wc), dot3(r2, wc));
+    const f3 eu = mk(1.0001f * (fabsf(r0.x) * hx + fabsf(r0.y) * hy), 1.0001f * (fabsf(r1.x) * hx + fabsf(r1.y) * hy),
+                     1.0001f * (fabsf(r2.x) * hx + fabsf(r2.y) * hy));
+    const float dumax = fmaxf(fmaxf(fabsf(duc.x) + eu.x, fabsf(duc.y) + eu.y), fabsf(duc.z) + eu.z);
+    const int ti = lnJ < n ? lnJ : 0;
+    const float4 c4 = S.c[ti];
+    const bool clear = primary_clear(duc, eu, dumax, xyz(c4), c4.w, xyz(S.pc[ti]), xyz(S.qc[ti]));
+    if (dumax < 1e30f) Kp_job &= ~ballot(clear);
+  }
   for (int k = 0; k < aa; ++k) {
     const int lnA = opaque(lane);
     // ---- phase 1: 64 primary rays, lnA = (pixel, AA sample) -----------------------------------------
@@ -318,23 +339,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
     const bool valid = x < P.W;
     Ray ray = primary_ray(P, x, y, a % P.aa_x, a / P.aa_x);
     bool lit = false, secondary = false;
-    unsigned long long Kp = n == 64 ? ~0ull : ((1ull << n) - 1ull);    // triangles a primary ray may hit
-    if (CULL) {
-      const float Xlo = (float)((x0 + k * PT) * P.aa_x) - ((float)P.W * (float)P.aa_x) / 2.0f;
-      const float Ylo = ((float)(y * P.aa_y) - ((float)P.H * (float)P.aa_y) / 2.0f) * P.sy;
-      const float hx = 0.5f * (float)(PT * P.aa_x - 1), hy = 0.5f * (float)(P.aa_y - 1) * P.sy;
-      const f3 wc = mk(Xlo + hx, Ylo + hy, P.focal);
-      const f3 r0 = mk(P.rot[0], P.rot[1], P.rot[2]), r1 = mk(P.rot[4], P.rot[5], P.rot[6]),
-               r2 = mk(P.rot[8], P.rot[9], P.rot[10]);
-      const f3 duc = mk(dot3(r0, wc), dot3(r1, wc), dot3(r2, wc));
-      const f3 eu = mk(1.0001f * (fabsf(r0.x) * hx + fabsf(r0.y) * hy), 1.0001f * (fabsf(r1.x) * hx + fabsf(r1.y) * hy),
-                       1.0001f * (fabsf(r2.x) * hx + fabsf(r2.y) * hy));
-      const float dumax = fmaxf(fmaxf(fabsf(duc.x) + eu.x, fabsf(duc.y) + eu.y), fabsf(duc.z) + eu.z);
-      const int ti = lnA < n ? lnA : 0;
-      const float4 c4 = S.c[ti];
-      const bool clear = primary_clear(duc, eu, dumax, xyz(c4), c4.w, xyz(S.pc[ti]), xyz(S.qc[ti]));
-      if (dumax < 1e30f) Kp &= ~ballot(clear);
-    }
+    const unsigned long long Kp = Kp_job;      // triangles a primary ray of this job may hit
     if (valid) {
       if (CULL) closest_hit_primary_masked(S, P, ray, Kp);
       else closest_hit_primary<false>(S, P, ray, wk);
