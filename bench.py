@@ -119,20 +119,45 @@ def main():
         gathered = torch.empty((world, rows, W), dtype=torch.int32, device=dev)
     frame = torch.empty((H, W), dtype=torch.int32, device=dev) if (rank == 0 and collective) else None
 
+    # N > 1 over RCCL: the render of frame k+1 runs on its own stream into the other of two stripe buffers while
+    # the bands of frame k are gathered and de-interleaved on the current stream (events order the hand-overs)
+    pipelined = collective and args.backend == "nccl"
+    if pipelined:
+        render_stream = torch.cuda.Stream(device=dev)
+        stripes = [stripe, torch.empty_like(stripe)]
+        rendered = [torch.cuda.Event(), torch.cuda.Event()]     # stripe i holds a finished frame
+        consumed = [None, None]                                 # the gather that read stripe i has finished
+    state = {"k": 0}
+
     def step(ev=None):
+        if pipelined:
+            i = state["k"] % 2
+            state["k"] += 1
+            cur = torch.cuda.current_stream()
+            if consumed[i] is not None:
+                render_stream.wait_event(consumed[i])
+            if ev:
+                ev[0].record(render_stream)
+            tracer.render_device(rot, cam, light, focal, stripes[i].data_ptr(), None, render_stream.cuda_stream)
+            if ev:
+                ev[1].record(render_stream)
+            rendered[i].record(render_stream)
+            cur.wait_event(rendered[i])
+            bands.gather_frame(stripes[i], world, rank, band_rows, gathered, frame, force=True)
+            consumed[i] = torch.cuda.Event()
+            consumed[i].record(cur)
+            return
         # the HIP kernel, enqueued on torch's current stream through the C ABI
         if ev:
             ev[0].record()
         tracer.render_device(rot, cam, light, focal, stripe.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
         if ev:
             ev[1].record()
-        # N > 1: one RCCL gather of the finished bands + de-interleave on rank 0; N == 1: the stripe IS the frame
+        # gloo rehearsal of N > 1: the bands travel via host memory; N == 1: the stripe IS the frame
         if args.backend == "gloo" and collective:
             host = bands.gather_frame(stripe.cpu(), world, rank, band_rows, force=True)
             if rank == 0:
                 frame.copy_(host)
-        elif collective:
-            bands.gather_frame(stripe, world, rank, band_rows, gathered, frame, force=True)
 
     def sync():
         if collective:
