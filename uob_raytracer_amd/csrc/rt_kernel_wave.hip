@@ -305,8 +305,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
   if (lane == 0) job = (int)atomicAdd(P.job_counter, 1u);
   job = __builtin_amdgcn_readfirstlane(job);
   if (job >= P.njobs) break;
-  const int lr = job / P.nseg;
-  const int x0 = (job - lr * P.nseg) * 64;
+  // Rows are handed out from the middle of the rank's rows outwards: segments differ 10x in cost, and the kernel
+  // ends when the last job does, so the last jobs should be cheap ones — the top and bottom rows of a view
+  // usually are (background, plain walls).
+  const int jrow = job / P.nseg;
+  const int mid = (P.owned_rows + 1) >> 1;
+  const int lr = (jrow & 1) ? mid + (jrow >> 1) : mid - 1 - (jrow >> 1);
+  const int x0 = (job - jrow * P.nseg) * 64;
   const int y = band_global_row(lr, P.band_rows, P.band_index, P.band_count);
   f3 outc = mk(0.f, 0.f, 0.f);
   // Triangles a primary ray of this job may hit, bounded once for the job's 64 x 1 pixels (all AA samples): the
@@ -568,7 +573,10 @@ static dim3 wave_grid(const FrameParams& P) {
     hipGetDevice(&dev);
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
   }
-  const int resident = cus * RT_MIN_WAVES;                       // workgroups the chip holds at once
+  // workgroups the chip holds at once; a rank of a multi-GPU job leaves one slot per CU free (registers and LDS
+  // for a workgroup of the collective's kernels), so that the gather of the previous frame can run beside it
+  const int per_cu = (P.band_count > 1 && !getenv("UOB_RT_FULL_GRID")) ? RT_MIN_WAVES - 1 : RT_MIN_WAVES;
+  const int resident = cus * per_cu;
   const int needed = (P.njobs + kWavesPerBlock - 1) / kWavesPerBlock;
   return dim3(needed < resident ? (needed > 0 ? needed : 1) : resident);
 }
