@@ -2,7 +2,7 @@ import os, sys
 sys.path.insert(0, '/root/repo')
 import torch, numpy as np
 from uob_raytracer_amd import abi, runtime as rt
-for bc in (1, 2):
+for bc in [int(v) for v in (sys.argv[1:] or ['1', '2'])]:
     # band_count 2 with band_rows = H/2... emulate: render only this rank's half but compare per-row cost
     cfg = abi.make_config(width=4096, height=4096, aa_x=4, aa_y=2, shadow_samples=64, band_rows=32, band_index=0, band_count=bc)
     tr = rt.RayTracer(cfg, rt.Scene.cornell_box())

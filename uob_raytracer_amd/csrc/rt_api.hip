@@ -66,7 +66,8 @@ struct rt_ctx {
   uint32_t* d_argb = nullptr;      // internal framebuffer for rt_render
   float4* d_rgb = nullptr;         // lazily allocated float tap
   unsigned long long* d_counters = nullptr;
-  unsigned int* d_jobctr = nullptr; // wave kernel's job counter
+  unsigned int* d_jobctr = nullptr; // wave kernel's job queue heads
+  int cus = 256;                    // compute units of the device
   float4* d_records = nullptr;     // staged records in HBM for meshes beyond one LDS stage
   // mesh kernel: per-frame candidate-tile masks (rt_kernel_mesh.hip) and the scene's bounding box for its world grid
   unsigned long long *d_screen_masks = nullptr, *d_world_masks = nullptr;
@@ -158,11 +159,12 @@ int rt_init(const rt_config* cfg, const float* vertices4, const float* normals4,
   if (hipSetDevice(c->device) != hipSuccess) { set_error("hipSetDevice(%d) failed", c->device); return fail(RT_E_DEVICE); }
   c->n = n;
   c->owned_rows = rt_config_owned_rows(cfg);
+  if (hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || c->cus < 1) c->cus = 256;
   const size_t nb = (size_t)(n > 0 ? n : 1) * sizeof(float4);
   const size_t px = (size_t)(c->owned_rows > 0 ? c->owned_rows : 1) * cfg->width;
   if (hipMalloc(&c->d_verts, 3 * nb) != hipSuccess || hipMalloc(&c->d_normals, nb) != hipSuccess ||
       hipMalloc(&c->d_colors, nb) != hipSuccess || hipMalloc(&c->d_argb, px * 4) != hipSuccess ||
-      hipMalloc(&c->d_counters, sizeof(rt_work)) != hipSuccess || hipMalloc(&c->d_jobctr, 64) != hipSuccess) {
+      hipMalloc(&c->d_counters, sizeof(rt_work)) != hipSuccess || hipMalloc(&c->d_jobctr, kJobHeads * kJobHeadStride * sizeof(unsigned int)) != hipSuccess) {
     set_error("hipMalloc failed: %s", hipGetErrorString(hipGetLastError())); return fail(RT_E_NOMEM);
   }
   if (n > 64 && hipMalloc(&c->d_records, (size_t)n * 8 * sizeof(float4)) != hipSuccess) {
@@ -230,8 +232,22 @@ static void fill_params(const rt_ctx* c, const float rot[12], const float cam[3]
   P->verts = c->d_verts; P->normals = c->d_normals; P->colors = c->d_colors;
   P->records = c->d_records;
   P->job_counter = c->d_jobctr;
-  P->nseg = (g.width + 63) / 64;
-  P->njobs = P->nseg * c->owned_rows;
+  {   // wave kernel: a job is a run of job_tasks 64-ray tasks (job_tasks * 64/aa pixels) of one row
+    const int aa = g.aa_x * g.aa_y;
+    const bool pow2 = aa >= 1 && aa <= 64 && 64 % aa == 0;
+    // Job size: 64 pixels, halved while the queue would hold fewer than ~64 jobs per resident wave (jobs differ
+    // 10x in cost; measured: 4096 rows -> 32 px, 1024 rows -> 16 px), but not below 16 pixels (per-job work:
+    // hand-out, primary bound, store).
+    const int pt = pow2 ? 64 / aa : 64;
+    const long waves = (long)c->cus * (g.band_count > 1 ? 4 : 5) * 4;
+    int jt = pow2 ? aa : 1;
+    while (jt > 1 && (jt / 2) * pt >= 16 && (long)((g.width + jt * pt - 1) / (jt * pt)) * c->owned_rows < 64 * waves) jt /= 2;
+    if (const char* e = getenv("UOB_RT_JOB_TASKS")) { const int v = atoi(e); if (pow2 && v >= 1 && v <= aa && aa % v == 0) jt = v; }
+    P->job_tasks = jt;
+    const int job_pixels = jt * pt;
+    P->nseg = (g.width + job_pixels - 1) / job_pixels;
+    P->njobs = P->nseg * c->owned_rows;
+  }
   if (c->d_screen_masks) {
     P->screen_masks = c->d_screen_masks; P->world_masks = c->d_world_masks;
     P->nwords = c->nwords; P->scx = c->scx; P->scy = c->scy; P->grid_g = kWorldGrid;

@@ -7,6 +7,11 @@
 
 namespace uobrt {
 
+// The wave kernel's job queue has several heads (a returning device-scope atomic on ONE word saturates at ~88
+// hand-outs per microsecond on this part): head h hands out the jobs h, h + kJobHeads, h + 2 kJobHeads, ...
+constexpr int kJobHeads = 32;
+constexpr int kJobHeadStride = 32;      // in 32-bit words: one 128-byte line per head
+
 struct DevSphere {
   float cx, cy, cz, r2;
   float col[4];
@@ -34,8 +39,9 @@ struct FrameParams {
   uint32_t* out_argb;     // owned_rows * W ARGB8888 words
   float4* out_rgb;        // nullable: owned_rows * W pre-quantisation colours
   unsigned long long* counters;  // nullable: rt_work, 8 x u64
-  unsigned int* job_counter;   // wave kernel: next 64-pixel segment to hand out (zeroed before each launch)
-  int32_t njobs, nseg;    // segments in total / per row
+  unsigned int* job_counter;   // wave kernel: kJobHeads queue heads, one per 128-B line (zeroed before each launch)
+  int32_t njobs, nseg;    // wave kernel: jobs in total / per row
+  int32_t job_tasks;      // wave kernel: 64-ray tasks per job (a job = job_tasks * 64 / aa consecutive pixels of a row)
   float4* records;        // staged triangle records in HBM (8 x n float4), used when n exceeds one LDS stage
   // mesh kernel: per-frame candidate-tile masks (rt_kernel_mesh.hip), nullptr = visit every tile
   unsigned long long* screen_masks;   // [scy][scx][nwords]: tiles a primary ray through that 64x64-pixel cell may hit

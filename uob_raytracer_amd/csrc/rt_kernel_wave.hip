@@ -300,18 +300,32 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
   RT_STAMP(0)                               // 0: staging + set-up
   Work wk, xw;                               // xw: executed-work counters of this wave (COUNT builds only)
   if (COUNT) for (int q = 0; q < 8; ++q) xw.v[q] = 0;
-  for (;;) {                                 // ---- job loop: one 64-pixel row segment per iteration ----------
+  // ---- job loop.  The queue has kJobHeads heads; a wave pulls from its home head until that one's jobs are
+  // gone, then walks on through the others (peeking with a load before spending an atomic), and leaves after a
+  // full round: every head only grows, so every wave reaches the exit.
+  int head = (int)((blockIdx.x * kWavesPerBlock + wave) % kJobHeads), heads_done = 0;
+  for (;;) {
   int job = 0;
-  if (lane == 0) job = (int)atomicAdd(P.job_counter, 1u);
-  job = __builtin_amdgcn_readfirstlane(job);
-  if (job >= P.njobs) break;
+  if (lane == 0) job = (int)atomicAdd(P.job_counter + head * kJobHeadStride, 1u);
+  job = __builtin_amdgcn_readfirstlane(job) * kJobHeads + head;
+  if (job >= P.njobs) {
+    bool found = false;
+    while (!found && ++heads_done < kJobHeads) {
+      head = head + 1 == kJobHeads ? 0 : head + 1;
+      const unsigned int at = __hip_atomic_load(P.job_counter + head * kJobHeadStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      found = (long long)at * kJobHeads + head < (long long)P.njobs;
+    }
+    if (!found) break;
+    continue;
+  }
   // Rows are handed out from the middle of the rank's rows outwards: segments differ 10x in cost, and the kernel
   // ends when the last job does, so the last jobs should be cheap ones — the top and bottom rows of a view
   // usually are (background, plain walls).
   const int jrow = job / P.nseg;
   const int mid = (P.owned_rows + 1) >> 1;
   const int lr = (jrow & 1) ? mid + (jrow >> 1) : mid - 1 - (jrow >> 1);
-  const int x0 = (job - jrow * P.nseg) * 64;
+  const int JP = P.job_tasks * PT;                 // pixels per job
+  const int x0 = (job - jrow * P.nseg) * JP;
   const int y = band_global_row(lr, P.band_rows, P.band_index, P.band_count);
   f3 outc = mk(0.f, 0.f, 0.f);
   // Triangles a primary ray of this job may hit, bounded once for the job's 64 x 1 pixels (all AA samples): the
@@ -322,7 +336,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
     const int lnJ = opaque(lane);
     const float Xlo = (float)(x0 * P.aa_x) - ((float)P.W * (float)P.aa_x) / 2.0f;
     const float Ylo = ((float)(y * P.aa_y) - ((float)P.H * (float)P.aa_y) / 2.0f) * P.sy;
-    const float hx = 0.5f * (float)(64 * P.aa_x - 1), hy = 0.5f * (float)(P.aa_y - 1) * P.sy;
+    const float hx = 0.5f * (float)(JP * P.aa_x - 1), hy = 0.5f * (float)(P.aa_y - 1) * P.sy;
     const f3 wc = mk(Xlo + hx, Ylo + hy, P.focal);
     const f3 r0 = mk(P.rot[0], P.rot[1], P.rot[2]), r1 = mk(P.rot[4], P.rot[5], P.rot[6]),
              r2 = mk(P.rot[8], P.rot[9], P.rot[10]);
@@ -335,7 +349,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
     const bool clear = primary_clear(duc, eu, dumax, xyz(c4), c4.w, xyz(S.pc[ti]), xyz(S.qc[ti]));
     if (dumax < 1e30f) Kp_job &= ~ballot(clear);
   }
-  for (int k = 0; k < aa; ++k) {
+  for (int k = 0; k < P.job_tasks; ++k) {
     const int lnA = opaque(lane);
     // ---- phase 1: 64 primary rays, lnA = (pixel, AA sample) -----------------------------------------
     const int pj = k * PT + (lnA >> la);       // pixel of this lnA within the 64-pixel job
@@ -529,9 +543,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
     }
     RT_STAMP(6)                             // 6: shading + AA sum
   }
-  // ---- store: 64 consecutive pixels, one coalesced access per wave ------------------------------------
+  // ---- store: the job's consecutive pixels, one coalesced access per wave ------------------------------
   const int x = x0 + lane;
-  if (!COUNT && !PROF && x < P.W) {
+  if (!COUNT && !PROF && lane < JP && x < P.W) {
     const float inv = (float)aa;
     const f3 c = mk(outc.x / inv, outc.y / inv, outc.z / inv);
     const size_t o = (size_t)lr * P.W + x;
@@ -582,7 +596,7 @@ static dim3 wave_grid(const FrameParams& P) {
 }
 
 void launch_wave_prof(const FrameParams& P, hipStream_t stream) {
-  hipMemsetAsync(P.job_counter, 0, sizeof(unsigned int), stream);
+  hipMemsetAsync(P.job_counter, 0, kJobHeads * kJobHeadStride * sizeof(unsigned int), stream);
   hipLaunchKernelGGL((rt_draw_wave<true, false, true>), wave_grid(P), dim3(64 * kWavesPerBlock), wave_kernel_lds(P, true), stream, P);
 }
 
@@ -590,7 +604,7 @@ void launch_wave(const FrameParams& P, bool cull, bool count, hipStream_t stream
   const dim3 block(64 * kWavesPerBlock);
   const dim3 grid = wave_grid(P);
   const size_t lds_bytes = wave_kernel_lds(P, cull);
-  hipMemsetAsync(P.job_counter, 0, sizeof(unsigned int), stream);
+  hipMemsetAsync(P.job_counter, 0, kJobHeads * kJobHeadStride * sizeof(unsigned int), stream);
   if (count) {
     if (cull) hipLaunchKernelGGL((rt_draw_wave<true, true>), grid, block, lds_bytes, stream, P);
     else hipLaunchKernelGGL((rt_draw_wave<false, true>), grid, block, lds_bytes, stream, P);
