@@ -68,6 +68,10 @@ struct rt_ctx {
   unsigned long long* d_counters = nullptr;
   unsigned int* d_jobctr = nullptr; // wave kernel's job queue heads
   int cus = 256;                    // compute units of the device
+  // wave kernel: last frame's expensive jobs go first (rt_device.h FrameParams::heavy_*); two lists, used in turn
+  unsigned int *d_heavy[2] = {nullptr, nullptr}, *d_heavy_flags = nullptr;
+  int heavy_cap = 0, heavy_phase = 0;
+  uint32_t heavy_gen = 0;
   float4* d_records = nullptr;     // staged records in HBM for meshes beyond one LDS stage
   // mesh kernel: per-frame candidate-tile masks (rt_kernel_mesh.hip) and the scene's bounding box for its world grid
   unsigned long long *d_screen_masks = nullptr, *d_world_masks = nullptr;
@@ -164,7 +168,7 @@ int rt_init(const rt_config* cfg, const float* vertices4, const float* normals4,
   const size_t px = (size_t)(c->owned_rows > 0 ? c->owned_rows : 1) * cfg->width;
   if (hipMalloc(&c->d_verts, 3 * nb) != hipSuccess || hipMalloc(&c->d_normals, nb) != hipSuccess ||
       hipMalloc(&c->d_colors, nb) != hipSuccess || hipMalloc(&c->d_argb, px * 4) != hipSuccess ||
-      hipMalloc(&c->d_counters, sizeof(rt_work)) != hipSuccess || hipMalloc(&c->d_jobctr, kJobHeads * kJobHeadStride * sizeof(unsigned int)) != hipSuccess) {
+      hipMalloc(&c->d_counters, sizeof(rt_work)) != hipSuccess || hipMalloc(&c->d_jobctr, (2 * kJobHeads + 2) * kJobHeadStride * sizeof(unsigned int)) != hipSuccess) {
     set_error("hipMalloc failed: %s", hipGetErrorString(hipGetLastError())); return fail(RT_E_NOMEM);
   }
   if (n > 64 && hipMalloc(&c->d_records, (size_t)n * 8 * sizeof(float4)) != hipSuccess) {
@@ -190,6 +194,21 @@ int rt_init(const rt_config* cfg, const float* vertices4, const float* normals4,
       for (int k = 0; k < 3; ++k) {
         c->box_lo[k] = fminf(c->box_lo[k], cfg->spheres[i].center[k] - r);
         c->box_hi[k] = fmaxf(c->box_hi[k], cfg->spheres[i].center[k] + r);
+      }
+    }
+  }
+  {   // wave kernel: lists of last frame's expensive jobs (sized for the smallest job, one 64-ray task)
+    const int aa = cfg->aa_x * cfg->aa_y;
+    const int pt = (aa >= 1 && aa <= 64 && 64 % aa == 0) ? 64 / aa : 64;
+    const size_t jobs_max = (size_t)((cfg->width + pt - 1) / pt) * (size_t)(c->owned_rows > 0 ? c->owned_rows : 1);
+    c->heavy_cap = (int)(jobs_max / 8 > 64 ? jobs_max / 8 : 64);
+    if (hipMemset(c->d_jobctr, 0, (2 * kJobHeads + 2) * kJobHeadStride * sizeof(unsigned int)) != hipSuccess) {
+      set_error("hipMemset failed: %s", hipGetErrorString(hipGetLastError())); return fail(RT_E_DEVICE);
+    }
+    if (n >= 1 && n <= 64) {
+      if (hipMalloc(&c->d_heavy[0], (size_t)c->heavy_cap * 4) != hipSuccess || hipMalloc(&c->d_heavy[1], (size_t)c->heavy_cap * 4) != hipSuccess ||
+          hipMalloc(&c->d_heavy_flags, jobs_max * 4) != hipSuccess || hipMemset(c->d_heavy_flags, 0, jobs_max * 4) != hipSuccess) {
+        set_error("hipMalloc failed: %s", hipGetErrorString(hipGetLastError())); return fail(RT_E_NOMEM);
       }
     }
   }
@@ -231,7 +250,7 @@ static void fill_params(const rt_ctx* c, const float rot[12], const float cam[3]
   }
   P->verts = c->d_verts; P->normals = c->d_normals; P->colors = c->d_colors;
   P->records = c->d_records;
-  P->job_counter = c->d_jobctr;
+  P->job_counter = c->d_jobctr + kJobHeadStride;      // [HeavyState 0 | queue heads | HeavyState 1], one line each
   {   // wave kernel: a job is a run of job_tasks 64-ray tasks (job_tasks * 64/aa pixels) of one row
     const int aa = g.aa_x * g.aa_y;
     const bool pow2 = aa >= 1 && aa <= 64 && 64 % aa == 0;
@@ -281,6 +300,17 @@ static int launch_frame(rt_ctx* c, const float rot[12], const float cam[3], cons
   HIP_TRY(hipEventRecord(c->ev0, stream));
   const bool wave_paths = !(c->cfg.flags & RT_FLAG_GENERIC_KERNEL);
   if (wave_paths && wave_kernel_supports(P)) {
+    if (c->d_heavy_flags && !getenv("UOB_RT_PLAIN_ORDER")) {       // last frame's expensive jobs first
+      const int prev = c->heavy_phase, cur = prev ^ 1;
+      unsigned int* const st[2] = {c->d_jobctr, c->d_jobctr + (2 * kJobHeads + 1) * kJobHeadStride};
+      P.heavy_prev = c->d_heavy[prev]; P.heavy_prev_state = st[prev];
+      P.heavy_new = c->d_heavy[cur]; P.heavy_new_state = st[cur];
+      P.heavy_flags = c->d_heavy_flags; P.heavy_gen = ++c->heavy_gen;
+      P.heavy_factor4 = 8;                                          // expensive = more than twice the average job
+      if (const char* e = getenv("UOB_RT_HEAVY_FACTOR4")) { const int v = atoi(e); if (v >= 1 && v <= 4096) P.heavy_factor4 = v; }
+      P.heavy_cap = P.njobs / 8 < c->heavy_cap ? P.njobs / 8 : c->heavy_cap;
+      c->heavy_phase = cur;
+    }
     launch_wave(P, !(c->cfg.flags & RT_FLAG_NO_CULL), false, stream);
   } else if (wave_paths && !(c->cfg.flags & RT_FLAG_NO_CULL) && mesh_kernel_supports(P)) {
     launch_stage_records(P, stream);        // per frame: the records hold camera-dependent terms
@@ -375,6 +405,7 @@ void rt_destroy(rt_ctx* c) {
   hipFree(c->d_verts); hipFree(c->d_normals); hipFree(c->d_colors);
   hipFree(c->d_argb); hipFree(c->d_rgb); hipFree(c->d_counters); hipFree(c->d_records); hipFree(c->d_jobctr);
   hipFree(c->d_screen_masks); hipFree(c->d_world_masks);
+  hipFree(c->d_heavy[0]); hipFree(c->d_heavy[1]); hipFree(c->d_heavy_flags);
   delete c;
 }
 

@@ -11,6 +11,9 @@ namespace uobrt {
 // hand-outs per microsecond on this part): head h hands out the jobs h, h + kJobHeads, h + 2 kJobHeads, ...
 constexpr int kJobHeads = 32;
 constexpr int kJobHeadStride = 32;      // in 32-bit words: one 128-byte line per head
+// HeavyState, in 32-bit words: [0] entries in the list, [2..3] sum of all job costs (64-bit, s_memtime ticks),
+// [4] jobs counted
+constexpr int kHeavyStateWords = 8;
 
 struct DevSphere {
   float cx, cy, cz, r2;
@@ -42,6 +45,17 @@ struct FrameParams {
   unsigned int* job_counter;   // wave kernel: kJobHeads queue heads, one per 128-B line (zeroed before each launch)
   int32_t njobs, nseg;    // wave kernel: jobs in total / per row
   int32_t job_tasks;      // wave kernel: 64-ray tasks per job (a job = job_tasks * 64 / aa consecutive pixels of a row)
+  // wave kernel: jobs that were expensive in the previous frame of this context are handed out first (the kernel
+  // ends when its last job does, so the long ones should start early); nullptr = plain order
+  const unsigned int* heavy_prev;     // their job ids
+  const unsigned int* heavy_prev_state;   // HeavyState of the previous frame
+  unsigned int* heavy_new;            // this frame's expensive jobs, appended as they finish
+  unsigned int* heavy_new_state;
+  unsigned int* heavy_flags;          // per job: the frame generation it was last listed FOR (gen = in heavy_prev;
+                                      // gen + 1 = listed again by this frame, i.e. already done)
+  uint32_t heavy_gen;
+  int32_t heavy_factor4;              // a job is expensive above heavy_factor4 / 4 times the average job cost
+  int32_t heavy_cap;
   float4* records;        // staged triangle records in HBM (8 x n float4), used when n exceeds one LDS stage
   // mesh kernel: per-frame candidate-tile masks (rt_kernel_mesh.hip), nullptr = visit every tile
   unsigned long long* screen_masks;   // [scy][scx][nwords]: tiles a primary ray through that 64x64-pixel cell may hit

@@ -304,20 +304,43 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
   // gone, then walks on through the others (peeking with a load before spending an atomic), and leaves after a
   // full round: every head only grows, so every wave reaches the exit.
   int head = (int)((blockIdx.x * kWavesPerBlock + wave) % kJobHeads), heads_done = 0;
+  // Longest jobs first: the jobs that cost more than 4x the average in the previous frame of this context are
+  // pulled (phase A, second set of heads) before the plain sequence (phase B, which skips them by a bitmap).
+  const bool lpt = !COUNT && !PROF && P.heavy_new != nullptr;
+  unsigned int n_heavy = 0u;
+  unsigned long long heavy_thr = ~0ull, cost_sum = 0ull;
+  unsigned int cost_jobs = 0u;
+  if (lpt) {
+    n_heavy = P.heavy_prev_state[0] < (unsigned int)P.heavy_cap ? P.heavy_prev_state[0] : (unsigned int)P.heavy_cap;
+    const unsigned long long psum = ((unsigned long long)P.heavy_prev_state[3] << 32) | P.heavy_prev_state[2];
+    const unsigned int pjobs = P.heavy_prev_state[4];
+    if (pjobs != 0u) heavy_thr = (unsigned long long)P.heavy_factor4 * (psum / pjobs) / 4ull;
+  }
+  bool phase_a = n_heavy != 0u;
   for (;;) {
   int job = 0;
-  if (lane == 0) job = (int)atomicAdd(P.job_counter + head * kJobHeadStride, 1u);
-  job = __builtin_amdgcn_readfirstlane(job) * kJobHeads + head;
-  if (job >= P.njobs) {
-    bool found = false;
-    while (!found && ++heads_done < kJobHeads) {
-      head = head + 1 == kJobHeads ? 0 : head + 1;
-      const unsigned int at = __hip_atomic_load(P.job_counter + head * kJobHeadStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      found = (long long)at * kJobHeads + head < (long long)P.njobs;
+  if (phase_a) {
+    if (lane == 0) job = (int)atomicAdd(P.job_counter + (kJobHeads + head) * kJobHeadStride, 1u);
+    const unsigned int slot = (unsigned int)__builtin_amdgcn_readfirstlane(job) * kJobHeads + (unsigned int)head;
+    if (slot >= n_heavy) { phase_a = false; continue; }
+    job = (int)P.heavy_prev[slot];
+    if (job < 0 || job >= P.njobs) continue;
+  } else {
+    if (lane == 0) job = (int)atomicAdd(P.job_counter + head * kJobHeadStride, 1u);
+    job = __builtin_amdgcn_readfirstlane(job) * kJobHeads + head;
+    if (job >= P.njobs) {
+      bool found = false;
+      while (!found && ++heads_done < kJobHeads) {
+        head = head + 1 == kJobHeads ? 0 : head + 1;
+        const unsigned int at = __hip_atomic_load(P.job_counter + head * kJobHeadStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        found = (long long)at * kJobHeads + head < (long long)P.njobs;
+      }
+      if (!found) break;
+      continue;
     }
-    if (!found) break;
-    continue;
+    if (n_heavy != 0u && P.heavy_flags[job] >= P.heavy_gen) continue;     // listed: taken care of by phase A
   }
+  const unsigned long long job_t0 = lpt ? __builtin_amdgcn_s_memtime() : 0ull;
   // Rows are handed out from the middle of the rank's rows outwards: segments differ 10x in cost, and the kernel
   // ends when the last job does, so the last jobs should be cheap ones — the top and bottom rows of a view
   // usually are (background, plain walls).
@@ -552,7 +575,19 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
     P.out_argb[o] = pack_argb(c);
     if (P.out_rgb) P.out_rgb[o] = make_float4(c.x, c.y, c.z, 1.0f);
   }
+  if (lpt) {
+    const unsigned long long cost = __builtin_amdgcn_s_memtime() - job_t0;
+    cost_sum += cost; cost_jobs += 1u;
+    if (cost > heavy_thr && lane == 0) {
+      const unsigned int at = atomicAdd(P.heavy_new_state, 1u);
+      if (at < (unsigned int)P.heavy_cap) { P.heavy_new[at] = (unsigned int)job; P.heavy_flags[job] = P.heavy_gen + 1u; }
+    }
+  }
   }                                          // ---- end of the job loop ---------------------------------------
+  if (lpt && lane == 0) {
+    atomicAdd(reinterpret_cast<unsigned long long*>(P.heavy_new_state + 2), cost_sum);
+    atomicAdd(P.heavy_new_state + 4, cost_jobs);
+  }
   if (PROF) {
     if (lane == 0) for (int q = 0; q < 8; ++q) atomicAdd(&P.counters[q], prof[q]);
     return;
@@ -596,7 +631,7 @@ static dim3 wave_grid(const FrameParams& P) {
 }
 
 void launch_wave_prof(const FrameParams& P, hipStream_t stream) {
-  hipMemsetAsync(P.job_counter, 0, kJobHeads * kJobHeadStride * sizeof(unsigned int), stream);
+  hipMemsetAsync(P.job_counter, 0, 2 * kJobHeads * kJobHeadStride * sizeof(unsigned int), stream);
   hipLaunchKernelGGL((rt_draw_wave<true, false, true>), wave_grid(P), dim3(64 * kWavesPerBlock), wave_kernel_lds(P, true), stream, P);
 }
 
@@ -604,7 +639,14 @@ void launch_wave(const FrameParams& P, bool cull, bool count, hipStream_t stream
   const dim3 block(64 * kWavesPerBlock);
   const dim3 grid = wave_grid(P);
   const size_t lds_bytes = wave_kernel_lds(P, cull);
-  hipMemsetAsync(P.job_counter, 0, kJobHeads * kJobHeadStride * sizeof(unsigned int), stream);
+  // one memset: the queue heads, and this frame's HeavyState, which lies directly before or behind them
+  const size_t heads_bytes = 2 * kJobHeads * kJobHeadStride * sizeof(unsigned int), state_bytes = kJobHeadStride * sizeof(unsigned int);
+  if (P.heavy_new != nullptr && !count) {
+    const bool before = P.heavy_new_state < P.job_counter;
+    hipMemsetAsync(before ? (void*)P.heavy_new_state : (void*)P.job_counter, 0, heads_bytes + state_bytes, stream);
+  } else {
+    hipMemsetAsync(P.job_counter, 0, heads_bytes, stream);
+  }
   if (count) {
     if (cull) hipLaunchKernelGGL((rt_draw_wave<true, true>), grid, block, lds_bytes, stream, P);
     else hipLaunchKernelGGL((rt_draw_wave<false, true>), grid, block, lds_bytes, stream, P);
