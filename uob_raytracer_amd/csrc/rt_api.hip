@@ -254,13 +254,13 @@ static void fill_params(const rt_ctx* c, const float rot[12], const float cam[3]
   {   // wave kernel: a job is a run of job_tasks 64-ray tasks (job_tasks * 64/aa pixels) of one row
     const int aa = g.aa_x * g.aa_y;
     const bool pow2 = aa >= 1 && aa <= 64 && 64 % aa == 0;
-    // Job size: 64 pixels, halved while the queue would hold fewer than ~64 jobs per resident wave (jobs differ
-    // 10x in cost; measured: 4096 rows -> 32 px, 1024 rows -> 16 px), but not below 16 pixels (per-job work:
-    // hand-out, primary bound, store).
+    // Job size: 64 pixels, halved while the queue would hold fewer than ~16 jobs per resident wave (jobs differ
+    // 10x in cost, but every hand-out stalls its wave for microseconds; measured with last frame's expensive jobs
+    // going first: 4096 and 2048 rows -> 64 px, 1024 and 512 rows -> 32 px), but not below 16 pixels.
     const int pt = pow2 ? 64 / aa : 64;
     const long waves = (long)c->cus * (g.band_count > 1 ? 4 : 5) * 4;
     int jt = pow2 ? aa : 1;
-    while (jt > 1 && (jt / 2) * pt >= 16 && (long)((g.width + jt * pt - 1) / (jt * pt)) * c->owned_rows < 64 * waves) jt /= 2;
+    while (jt > 1 && (jt / 2) * pt >= 16 && (long)((g.width + jt * pt - 1) / (jt * pt)) * c->owned_rows < 16 * waves) jt /= 2;
     if (const char* e = getenv("UOB_RT_JOB_TASKS")) { const int v = atoi(e); if (pow2 && v >= 1 && v <= aa && aa % v == 0) jt = v; }
     P->job_tasks = jt;
     const int job_pixels = jt * pt;
@@ -300,7 +300,9 @@ static int launch_frame(rt_ctx* c, const float rot[12], const float cam[3], cons
   HIP_TRY(hipEventRecord(c->ev0, stream));
   const bool wave_paths = !(c->cfg.flags & RT_FLAG_GENERIC_KERNEL);
   if (wave_paths && wave_kernel_supports(P)) {
-    if (c->d_heavy_flags && !getenv("UOB_RT_PLAIN_ORDER")) {       // last frame's expensive jobs first
+    // last frame's expensive jobs first — where jobs are long enough (4+ tasks) for the extra look-up per
+    // hand-out not to matter (measured: 1024^2 frames with 16-pixel jobs lose 12-18 % to it, larger ones gain 2-8 %)
+    if (c->d_heavy_flags && P.job_tasks >= 4 && !getenv("UOB_RT_PLAIN_ORDER")) {
       const int prev = c->heavy_phase, cur = prev ^ 1;
       unsigned int* const st[2] = {c->d_jobctr, c->d_jobctr + (2 * kJobHeads + 1) * kJobHeadStride};
       P.heavy_prev = c->d_heavy[prev]; P.heavy_prev_state = st[prev];
