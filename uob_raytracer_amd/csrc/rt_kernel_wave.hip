@@ -8,8 +8,9 @@
 // (t first, u/v only if t passes, :266) is a WAVE-UNIFORM branch, lane predicates are 64-bit wave masks
 // (one v_cmp each, logic on the scalar unit) and the any-hit early-out is "blocked mask == all ones".
 //
-// A wave owns 64 consecutive pixels of one image row (its framebuffer store is one coalesced 256-B ARGB /
-// 1-KiB float4 access) and walks them in `aa` tasks of 64 primary rays (64/aa pixels x aa AA rays):
+// Persistent waves pull JOBS from a multi-headed queue (see the job loop): a job is up to 64 consecutive pixels
+// of one image row (its framebuffer store is one coalesced access), walked in tasks of 64 primary rays
+// (64/aa pixels x aa AA rays):
 //   phase 1  primary rays, lane = (pixel, AA sample);  phase 2  mirror/glass bounces (kernels.cl:342-365)
 //   phase 3  shadows of the 64 surface points (below);  phase 4  shading, AA sum in the reference's order.
 //
