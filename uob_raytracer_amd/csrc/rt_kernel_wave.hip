@@ -388,8 +388,54 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
       else closest_hit_primary<false>(S, P, ray, wk);
       if (ray.tri != -1) {
         // ---- phase 2: mirror / glass bounces (kernels.cl:342-365) -----------------------------------
-        if (ray.col.w <= 0.0f) { secondary = true; lit = bounce_to_diffuse<false>(S, P, ray, wk); }
+        if (ray.col.w <= 0.0f) { secondary = true; if (!CULL) lit = bounce_to_diffuse<false>(S, P, ray, wk); }
         else lit = true;
+      }
+    }
+    if (CULL) {
+      // The bounce loop of secondary_light (:342-365) run by the whole wave, so that each round's closest-hit
+      // search visits only the triangles its rays can reach: the bounce rays of neighbouring pixels leave a
+      // smooth surface nearby in similar directions, and one lane = triangle bound over their origin box and
+      // direction box (task_bound with the distance rule off) usually leaves a handful of the scene's triangles.
+      bool bouncing = secondary;
+      for (int b = 0; b < P.bounces; ++b) {
+        const bool act = bouncing && ray.col.w <= 0.0f;               // this lane's loop condition, :345
+        const unsigned long long actm = ballot(act);
+        if (actm == 0ull) break;
+        if (act) ray = (ray.col.w == 0.0f) ? reflect_ray(ray) : refract_ray(ray);
+        unsigned long long Kb = n == 64 ? ~0ull : ((1ull << n) - 1ull);
+        {
+          const int lnK = opaque(lane);
+          const f3 o = ray.start, d = ray.dir;
+          const float mag = fmaxf(fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)), fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fabsf(d.z)));
+          const bool fin = act && mag < 1e30f;                         // false for NaN as well
+          const bool isnan_ = act && !(mag == mag);                    // a NaN ray hits nothing whatever the set
+          const unsigned long long finm = ballot(fin);
+          if (finm != 0ull && ballot(act && !fin && !isnan_) == 0ull) {
+            const float big = 3.0e38f;
+            const f3 olo = mk(wave_min(fin ? o.x : big), wave_min(fin ? o.y : big), wave_min(fin ? o.z : big));
+            const f3 ohi = mk(wave_max(fin ? o.x : -big), wave_max(fin ? o.y : -big), wave_max(fin ? o.z : -big));
+            const f3 dlo = mk(wave_min(fin ? d.x : big), wave_min(fin ? d.y : big), wave_min(fin ? d.z : big));
+            const f3 dhi = mk(wave_max(fin ? d.x : -big), wave_max(fin ? d.y : -big), wave_max(fin ? d.z : -big));
+            const f3 s0 = 0.5f * (olo + ohi), D0 = 0.5f * (dlo + dhi);
+            const float es = 0.5001f * fmaxf(fmaxf(ohi.x - olo.x, ohi.y - olo.y), ohi.z - olo.z) + 1e-6f * norm1(s0);
+            const float ed = 0.5001f * fmaxf(fmaxf(dhi.x - dlo.x, dhi.y - dlo.y), dhi.z - dlo.z) + 1e-6f * norm1(D0);
+            const float dmx = fmaxf(fmaxf(fmaxf(fabsf(dlo.x), fabsf(dhi.x)), fmaxf(fabsf(dlo.y), fabsf(dhi.y))), fmaxf(fabsf(dlo.z), fabsf(dhi.z)));
+            TriLane Tb;
+            const int tb_i = lnK < n ? lnK : 0;
+            Tb.v0 = xyz(S.v0[tb_i]); Tb.e1 = xyz(S.e1[tb_i]); Tb.e2 = xyz(S.e2[tb_i]); Tb.c = xyz(S.c[tb_i]);
+            Tb.c1 = norm1(Tb.c); Tb.e1_1 = norm1(Tb.e1); Tb.e2_1 = norm1(Tb.e2);
+            const float dl = 1.7321f * dmx * 1.0001f;                   // >= |d|_2 of every ray
+            const Bound bb = task_bound(Tb, s0, D0, es, ed, 2e-6f * dl, 0.0f, dl);
+            Kb &= ~ballot(bb.clear);
+          } else if (finm == 0ull) {
+            Kb = 0ull;                                                  // only NaN rays: they hit nothing
+          }
+        }
+        if (act) {
+          closest_hit_masked(S, P, ray, Kb);
+          if (ray.tri != -1 && ray.col.w > 0.0f) { lit = true; bouncing = false; }
+        }
       }
     }
     RT_STAMP(1)                             // 1: primary rays + bounces

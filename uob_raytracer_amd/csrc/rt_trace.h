@@ -177,6 +177,34 @@ __device__ inline void closest_hit_primary_masked(const LdsScene& S, const Frame
   closest_spheres<false>(P, ray, current_t, wk);
 }
 
+// closest_hit restricted to the triangles in `mask`, visited in index order (ties on t resolve as in the full loop)
+__device__ inline void closest_hit_masked(const LdsScene& S, const FrameParams& P, Ray& ray, unsigned long long mask) {
+  float current_t = RT_MAXFLOAT;
+  const f3 nd = -ray.dir;
+  float bu = 0.f, bv = 0.f;
+  int best = -1;
+  for (; mask != 0ull; mask &= mask - 1ull) {
+    const int i = __builtin_ctzll(mask);
+    const f3 v0 = xyz(S.v0[i]), e1 = xyz(S.e1[i]), e2 = xyz(S.e2[i]), c = xyz(S.c[i]);
+    const f3 b = ray.start - v0;
+    const float detA_recip = rcp_exact(detc(nd, c));
+    const float t = detc(b, c) * detA_recip;
+    const float u = detc(nd, cof(b, e2)) * detA_recip;
+    const float v = detc(nd, cof(e1, b)) * detA_recip;
+    if (t < current_t && u >= 0 && v >= 0 && (u + v) <= 1 && t >= 0) {
+      best = i; bu = u; bv = v; current_t = t;
+    }
+  }
+  if (best >= 0) {
+    ray.tri = best;
+    ray.P = (xyz(S.v0[best]) + bu * xyz(S.e1[best])) + bv * xyz(S.e2[best]);
+    ray.N = xyz(S.nrm[best]);
+    ray.col = S.col[best];
+  }
+  Work wk;
+  closest_spheres<false>(P, ray, current_t, wk);
+}
+
 // Sphere part of the shadow test, kernels.cl:278-307
 template <bool COUNT>
 __device__ __forceinline__ bool shadow_spheres(const FrameParams& P, f3 start, f3 dir, float radius_sq, Work& wk) {
