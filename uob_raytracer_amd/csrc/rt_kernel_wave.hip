@@ -309,8 +309,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
   // pulled (phase A, second set of heads) before the plain sequence (phase B, which skips them by a bitmap).
   const bool lpt = !COUNT && !PROF && P.heavy_new != nullptr;
   unsigned int n_heavy = 0u;
-  unsigned long long heavy_thr = ~0ull, cost_sum = 0ull;
-  unsigned int cost_jobs = 0u;
+  unsigned long long heavy_thr = ~0ull;
+  // this wave's sum of job costs and job count live in the padding words of its RNG scratch (kept in registers
+  // they were spilled: 768 B of scratch traffic per job)
+  unsigned long long* const cost_acc = reinterpret_cast<unsigned long long*>(L.rng + 256);
+  if (lpt && lane == 0) { cost_acc[0] = 0ull; cost_acc[1] = 0ull; }
   if (lpt) {
     n_heavy = P.heavy_prev_state[0] < (unsigned int)P.heavy_cap ? P.heavy_prev_state[0] : (unsigned int)P.heavy_cap;
     const unsigned long long psum = ((unsigned long long)P.heavy_prev_state[3] << 32) | P.heavy_prev_state[2];
@@ -624,7 +627,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
   }
   if (lpt) {
     const unsigned long long cost = __builtin_amdgcn_s_memtime() - job_t0;
-    cost_sum += cost; cost_jobs += 1u;
+    if (lane == 0) { cost_acc[0] += cost; cost_acc[1] += 1ull; }
     if (cost > heavy_thr && lane == 0) {
       const unsigned int at = atomicAdd(P.heavy_new_state, 1u);
       if (at < (unsigned int)P.heavy_cap) { P.heavy_new[at] = (unsigned int)job; P.heavy_flags[job] = P.heavy_gen + 1u; }
@@ -632,8 +635,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
   }
   }                                          // ---- end of the job loop ---------------------------------------
   if (lpt && lane == 0) {
-    atomicAdd(reinterpret_cast<unsigned long long*>(P.heavy_new_state + 2), cost_sum);
-    atomicAdd(P.heavy_new_state + 4, cost_jobs);
+    atomicAdd(reinterpret_cast<unsigned long long*>(P.heavy_new_state + 2), cost_acc[0]);
+    atomicAdd(P.heavy_new_state + 4, (unsigned int)cost_acc[1]);
   }
   if (PROF) {
     if (lane == 0) for (int q = 0; q < 8; ++q) atomicAdd(&P.counters[q], prof[q]);
