@@ -217,7 +217,7 @@ __global__ __launch_bounds__(64 * kMeshWaves) void rt_bin_shadow(const FramePara
     const float cinf = fmaxf(fmaxf(fabsf(C.x), fabsf(C.y)), fabsf(C.z));
     const float hs = 1.001f * h + 1e-5f * (1.0f + cinf);
     const f3 D0 = light - C;
-    const float d0len = sqrtf(dot3(D0, D0));
+    const float d0len = bsqrt(dot3(D0, D0));
     const float dinf = fmaxf(fmaxf(fabsf(D0.x), fabsf(D0.y)), fabsf(D0.z));
     const float ed = hs + 1.1e-4f * (d0len + 2.0f * hs) + 1e-6f * (1.0f + dinf + cinf);
     const float dlen_max = (d0len + 1.7321f * ed) * 1.00001f;
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
 
     // ---- phase 3: shadows over all tiles ---------------------------------------------------------------
     const unsigned long long litmask = ballot(lit);
-    const float dlen = sqrtf(radius_sq);
+    const float dlen = bsqrt(radius_sq);
     const float hh = 1.002f * hbox + 2e-6f * (dlen + hbox);
     float dminlen = dlen - 1.7321f * hh;
     const bool sane = lit && (radius_sq > 1e-18f) && (radius_sq < 1e30f);

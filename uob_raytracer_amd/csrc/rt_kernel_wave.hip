@@ -459,7 +459,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
     unsigned long long K = tri_lanes, need = ~0ull, sphmask = P.nsph > 0 ? ~0ull : 0ull;
     if (CULL && work != 0ull) {
       // bounds used by the cull (never by the shading): |dir|, jitter half-width with rounding slack
-      const float dlen = sqrtf(radius_sq);
+      const float dlen = bsqrt(radius_sq);
       const float hh = 1.002f * hbox + 2e-6f * (dlen + hbox);
       float dminlen = dlen - 1.7321f * hh;
       const bool sane = lit && (radius_sq > 1e-18f) && (radius_sq < 1e30f);

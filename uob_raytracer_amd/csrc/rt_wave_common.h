@@ -24,6 +24,10 @@ __device__ __forceinline__ int opaque(int v) {
 }
 __device__ __forceinline__ unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ float norm1(f3 a) { return fabsf(a.x) + fabsf(a.y) + fabsf(a.z); }
+// Square root for the BOUNDS only (never for a value of the reference's arithmetic): v_sqrt_f32, 1 ulp, one
+// instruction instead of the ~12 of the correctly rounded sqrtf.  Every bound that uses it carries a relative
+// slack of at least 1e-6.
+__device__ __forceinline__ float bsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 // Wave-wide reductions.  The result is the same in every lane; readfirstlane tells the compiler so
 // (otherwise everything derived from it — the candidate masks, the loops over them — is treated as
 // divergent and kept in VGPRs with exec-mask loops).
@@ -235,7 +239,7 @@ __device__ __forceinline__ bool sphere_bundle_maybe(const FrameParams& P, f3 o, 
     if (casters_only && sp.col[3] == -1.0f) continue;
     const f3 Lv = o - mk(sp.cx, sp.cy, sp.cz);
     const f3 cr = mk(Lv.y * dir.z - Lv.z * dir.y, Lv.z * dir.x - Lv.x * dir.z, Lv.x * dir.y - Lv.y * dir.x);
-    const float crn = sqrtf(dot3(cr, cr)), Ln = sqrtf(dot3(Lv, Lv)), R = sqrtf(fmaxf(sp.r2, 0.0f));
+    const float crn = bsqrt(dot3(cr, cr)), Ln = bsqrt(dot3(Lv, Lv)), R = bsqrt(fmaxf(sp.r2, 0.0f));
     const bool miss = (crn - Ln * jm > R * (dlen + jm) * 1.002f) && (Ln < 40.0f * R) && (sp.r2 > 0.0f);
     maybe = maybe || !miss;
   }
@@ -261,7 +265,7 @@ __device__ __forceinline__ SphereBound spheres_point(const FrameParams& P, f3 st
     const f3 Lv = start - mk(sp.cx, sp.cy, sp.cz);
     const f3 cr = mk(Lv.y * dir.z - Lv.z * dir.y, Lv.z * dir.x - Lv.x * dir.z, Lv.x * dir.y - Lv.y * dir.x);
     const f3 cl = mk(cr.y * Lv.z - cr.z * Lv.y, cr.z * Lv.x - cr.x * Lv.z, cr.x * Lv.y - cr.y * Lv.x);     // cr x L
-    const float crn = sqrtf(dot3(cr, cr)), Ln2 = dot3(Lv, Lv), Ln = sqrtf(Ln2), R = sqrtf(fmaxf(sp.r2, 0.0f));
+    const float crn = bsqrt(dot3(cr, cr)), Ln2 = dot3(Lv, Lv), Ln = bsqrt(Ln2), R = bsqrt(fmaxf(sp.r2, 0.0f));
     const bool near = (Ln < 40.0f * R) && (sp.r2 > 0.0f);
     const bool miss = near && (crn * crn - hh * norm1(cl) > R * (dlen + jm) * 1.002f * crn);
     r.maybe = r.maybe || !miss;
