@@ -266,6 +266,10 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
   float4* tile = lds;                                   // kBatch staged tiles x 4 records x kTile triangles
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
+  // workgroup rows are dispatched from the middle of the frame outwards: the last workgroups to start are the
+  // top and bottom ones, usually the cheap ones (the kernel ends when the last workgroup does)
+  const int wg_mid = ((int)gridDim.y + 1) >> 1;
+  const int wg_row = (blockIdx.y & 1) ? wg_mid + (int)(blockIdx.y >> 1) : wg_mid - 1 - (int)(blockIdx.y >> 1);
   const int wave_bytes = mesh_wave_lds_bytes(P.S > kPointSamples || P.nsph > 0);
   char* const wbase = reinterpret_cast<char*>(lds + kBatch * kSlot) + wave * wave_bytes;
   const MeshWaveLds L{reinterpret_cast<float4*>(wbase), reinterpret_cast<float4*>(wbase + 64 * 16),
@@ -283,7 +287,7 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
       const int cx = (blockIdx.x * 16) >> kScreenCellLog;
       int last = -1;
       for (int r = 0; r < 16; ++r) {                      // the workgroup's 16 packed rows: global y may jump at a band edge
-        const int lrr = blockIdx.y * 16 + r;
+        const int lrr = wg_row * 16 + r;
         if (lrr >= P.owned_rows) break;
         const int cy = band_global_row(lrr, P.band_rows, P.band_index, P.band_count) >> kScreenCellLog;
         if (cy != last) m |= P.screen_masks[((size_t)cy * P.scx + cx) * nwords + w];
@@ -300,7 +304,7 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
   const int PT = 64 >> la;                              // pixels per task
   BlockGeom B;
   B.x0 = blockIdx.x * 16 + (wave & 1) * 8;
-  B.lr0 = blockIdx.y * 16 + (wave >> 1) * 8;            // waves past the frame still walk the tiles (barriers)
+  B.lr0 = wg_row * 16 + (wave >> 1) * 8;                // waves past the frame still walk the tiles (barriers)
   B.ptx_log = (6 - la + 1) >> 1;                        // PTx >= PTy, PTx * PTy = PT
   B.pty_log = (6 - la) - B.ptx_log;
   const int GP = PT < kRngPixels ? PT : kRngPixels;
