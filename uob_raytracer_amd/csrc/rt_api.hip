@@ -37,6 +37,7 @@ void launch_stage_records(const FrameParams& P, hipStream_t stream);
 void launch_mesh(const FrameParams& P, bool count, hipStream_t stream);
 bool mesh_kernel_supports(const FrameParams& P);
 int mesh_tiles(int n);
+int mesh_occ_words(int grid);
 int mesh_screen_cells(int pixels);
 void launch_wave(const FrameParams& P, bool cull, bool count, hipStream_t stream);
 void launch_wave_prof(const FrameParams& P, hipStream_t stream);
@@ -75,6 +76,7 @@ struct rt_ctx {
   float4* d_records = nullptr;     // staged records in HBM for meshes beyond one LDS stage
   // mesh kernel: per-frame candidate-tile masks (rt_kernel_mesh.hip) and the scene's bounding box for its world grid
   unsigned long long *d_screen_masks = nullptr, *d_world_masks = nullptr;
+  unsigned int* d_world_occ = nullptr;
   int nwords = 0, scx = 0, scy = 0;
   float box_lo[3] = {0, 0, 0}, box_hi[3] = {0, 0, 0};
   hipStream_t stream = nullptr;
@@ -179,7 +181,8 @@ int rt_init(const rt_config* cfg, const float* vertices4, const float* normals4,
     c->scx = mesh_screen_cells(cfg->width); c->scy = mesh_screen_cells(cfg->height);
     const size_t g3 = (size_t)kWorldGrid * kWorldGrid * kWorldGrid;
     if (hipMalloc(&c->d_screen_masks, (size_t)c->scx * c->scy * c->nwords * 8) != hipSuccess ||
-        hipMalloc(&c->d_world_masks, g3 * c->nwords * 8) != hipSuccess) {
+        hipMalloc(&c->d_world_masks, g3 * c->nwords * 8) != hipSuccess ||
+        hipMalloc(&c->d_world_occ, (size_t)mesh_occ_words(kWorldGrid) * sizeof(unsigned int)) != hipSuccess) {
       set_error("hipMalloc failed: %s", hipGetErrorString(hipGetLastError())); return fail(RT_E_NOMEM);
     }
     // every surface point lies on a triangle or a sphere: their bounding box (the world grid spans it)
@@ -268,7 +271,7 @@ static void fill_params(const rt_ctx* c, const float rot[12], const float cam[3]
     P->njobs = P->nseg * c->owned_rows;
   }
   if (c->d_screen_masks) {
-    P->screen_masks = c->d_screen_masks; P->world_masks = c->d_world_masks;
+    P->screen_masks = c->d_screen_masks; P->world_masks = c->d_world_masks; P->world_occ = c->d_world_occ;
     P->nwords = c->nwords; P->scx = c->scx; P->scy = c->scy; P->grid_g = kWorldGrid;
     // World grid: a cube over the scene box, grown so that every shadow-ray start point X + 1e-4 (light - X)
     // of a surface point X in the box (kernels.cl:324) stays inside, rounding included.
@@ -406,7 +409,7 @@ void rt_destroy(rt_ctx* c) {
   if (c->ev1) hipEventDestroy(c->ev1);
   hipFree(c->d_verts); hipFree(c->d_normals); hipFree(c->d_colors);
   hipFree(c->d_argb); hipFree(c->d_rgb); hipFree(c->d_counters); hipFree(c->d_records); hipFree(c->d_jobctr);
-  hipFree(c->d_screen_masks); hipFree(c->d_world_masks);
+  hipFree(c->d_screen_masks); hipFree(c->d_world_masks); hipFree(c->d_world_occ);
   hipFree(c->d_heavy[0]); hipFree(c->d_heavy[1]); hipFree(c->d_heavy_flags);
   delete c;
 }

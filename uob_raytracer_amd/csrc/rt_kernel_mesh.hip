@@ -191,6 +191,81 @@ __global__ __launch_bounds__(64 * kMeshWaves) void rt_bin_primary(const FramePar
   }
 }
 
+// Words of the three occupancy bitmaps (cells of edge 1, 2 and 4 grid cells), one after the other
+__host__ __device__ inline int occ_offset(int G, int level) {
+  const int w0 = (G * G * G + 31) / 32, w1 = ((G / 2) * (G / 2) * (G / 2) + 31) / 32;
+  return level == 0 ? 0 : level == 1 ? w0 : w0 + w1;
+}
+__host__ __device__ inline int occ_words(int G) { return occ_offset(G, 2) + ((G / 4) * (G / 4) * (G / 4) + 31) / 32; }
+
+// Which world cells can hold the start point of a shadow ray at all: every surface point lies on a triangle or on
+// a sphere, and its start point X + 1e-4 (light - X) within 1e-4 |light - X| of it.  One thread per triangle (then
+// per sphere) marks the cells its bounding box touches, widened by that distance, by the rounding of world_cell()
+// and by 1 % of a cell; rt_bin_shadow skips every other cell (no task ever reads their masks).
+__global__ __launch_bounds__(256) void rt_bin_occupancy(const FrameParams P) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int G = P.grid_g;
+  f3 lo, hi;
+  if (i < P.n) {
+    const f3 a0 = xyz(P.records[i]), a1 = a0 + xyz(P.records[(size_t)P.n + i]), a2 = a0 + xyz(P.records[(size_t)2 * P.n + i]);
+    lo = mk(fminf(fminf(a0.x, a1.x), a2.x), fminf(fminf(a0.y, a1.y), a2.y), fminf(fminf(a0.z, a1.z), a2.z));
+    hi = mk(fmaxf(fmaxf(a0.x, a1.x), a2.x), fmaxf(fmaxf(a0.y, a1.y), a2.y), fmaxf(fmaxf(a0.z, a1.z), a2.z));
+  } else if (i < P.n + P.nsph) {
+    const DevSphere& sp = P.sph[i - P.n];
+    const float r = sqrtf(fmaxf(sp.r2, 0.0f)) * 1.0001f;
+    lo = mk(sp.cx - r, sp.cy - r, sp.cz - r); hi = mk(sp.cx + r, sp.cy + r, sp.cz + r);
+  } else {
+    lo = mk(0.f, 0.f, 0.f); hi = lo;
+  }
+  bool valid = i < P.n + P.nsph;
+  const float amax = fmaxf(fmaxf(fmaxf(fabsf(lo.x), fabsf(hi.x)), fmaxf(fabsf(lo.y), fabsf(hi.y))), fmaxf(fabsf(lo.z), fabsf(hi.z)));
+  const float lmax = fmaxf(fmaxf(fabsf(P.light[0]), fabsf(P.light[1])), fabsf(P.light[2]));
+  const float sl = 2e-4f * (lmax + amax) + 1e-5f * (1.0f + amax);
+  if (!(amax < 1e30f)) valid = false;               // non-finite vertices: no ray can hit such a triangle
+  int c0[3], c1[3];
+  const float lo3[3] = {lo.x, lo.y, lo.z}, hi3[3] = {hi.x, hi.y, hi.z};
+  for (int k = 0; k < 3; ++k) {
+    const float f0 = floorf((lo3[k] - sl - P.grid_lo[k]) * P.grid_inv - 0.01f), f1 = floorf((hi3[k] + sl - P.grid_lo[k]) * P.grid_inv + 0.01f);
+    c0[k] = f0 < 0.0f ? 0 : (f0 > (float)(G - 1) ? G - 1 : (int)f0);
+    c1[k] = f1 < 0.0f ? 0 : (f1 > (float)(G - 1) ? G - 1 : (int)f1);
+  }
+  // A mesh puts tens of thousands of triangles into a few cells: the lanes of a wave that touch one cell only
+  // combine their bits and send one atomic per distinct word (atomics on one address are serialised memory-side)
+  const bool single = valid && c0[0] == c1[0] && c0[1] == c1[1] && c0[2] == c1[2];
+  for (int level = 0; level < 3; ++level) {
+    const int g = G >> level;
+    unsigned int* occ = P.world_occ + occ_offset(G, level);
+    const int cell = (((c0[2] >> level) * g + (c0[1] >> level)) * g + (c0[0] >> level));
+    const int word = single ? (cell >> 5) : -1;
+    const unsigned int bit = single ? (1u << (cell & 31)) : 0u;
+    for (unsigned long long rem = ballot(single); rem != 0ull;) {
+      const int src = __builtin_ctzll(rem);
+      const int w = __builtin_amdgcn_readlane(word, src);
+      const unsigned long long same = ballot(word == w);
+      unsigned int m = word == w ? bit : 0u;
+      for (int off = 32; off > 0; off >>= 1) m |= (unsigned int)__shfl_xor((int)m, off, 64);
+      if ((threadIdx.x & 63) == src) atomicOr(&occ[w], m);
+      rem &= ~same;
+    }
+    if (valid && !single)
+      for (int z = c0[2] >> level; z <= (c1[2] >> level); ++z)
+        for (int y = c0[1] >> level; y <= (c1[1] >> level); ++y) {        // the cells of one x-run are consecutive bits
+          const int b0 = (z * g + y) * g + (c0[0] >> level), b1 = (z * g + y) * g + (c1[0] >> level);
+          for (int w = b0 >> 5; w <= (b1 >> 5); ++w) {
+            const int lo_b = w == (b0 >> 5) ? (b0 & 31) : 0, hi_b = w == (b1 >> 5) ? (b1 & 31) : 31;
+            const unsigned int m = (hi_b - lo_b == 31 ? ~0u : ((1u << (hi_b - lo_b + 1)) - 1u)) << lo_b;
+            atomicOr(&occ[w], m);
+          }
+        }
+  }
+}
+
+__device__ __forceinline__ bool occupied(const FrameParams& P, int level, int ix, int iy, int iz) {
+  const int g = P.grid_g >> level;
+  const int cell = (iz * g + iy) * g + ix;
+  return ((P.world_occ[occ_offset(P.grid_g, level) + (cell >> 5)] >> (cell & 31)) & 1u) != 0u;
+}
+
 // Grid: x = tiles / 4, y = z-slice of the world grid.
 __global__ __launch_bounds__(64 * kMeshWaves) void rt_bin_shadow(const FrameParams P) {
   const int lane = threadIdx.x & 63;
@@ -232,12 +307,15 @@ __global__ __launch_bounds__(64 * kMeshWaves) void rt_bin_shadow(const FramePara
   };
   const int Gq = G >> 2, izq = blockIdx.z, iyq = blockIdx.y;         // one row of coarsest cells per wave
   for (int ixq = 0; ixq < Gq; ++ixq) {
+      if (!occupied(P, 2, ixq, iyq, izq)) continue;
       if (ballot(ok && !cell_clear(centre(ixq, iyq, izq, 4.0f * P.grid_cell), 4.0f * half)) == 0ull) continue;
       for (int s2 = 0; s2 < 8; ++s2) {
         const int ixc = 2 * ixq + (s2 & 1), iyc = 2 * iyq + ((s2 >> 1) & 1), izc = 2 * izq + (s2 >> 2);
+        if (!occupied(P, 1, ixc, iyc, izc)) continue;
         if (ballot(ok && !cell_clear(centre(ixc, iyc, izc, 2.0f * P.grid_cell), 2.0f * half)) == 0ull) continue;
         for (int sub = 0; sub < 8; ++sub) {
           const int ix = 2 * ixc + (sub & 1), iy = 2 * iyc + ((sub >> 1) & 1), iz = 2 * izc + (sub >> 2);
+          if (!occupied(P, 0, ix, iy, iz)) continue;
           const unsigned long long m = ballot(ok && !cell_clear(centre(ix, iy, iz, P.grid_cell), half));
           if (m != 0ull && lane == 0)
             atomicOr(&P.world_masks[((size_t)(iz * G + iy) * G + ix) * P.nwords + (t >> 6)], 1ull << (t & 63));
@@ -724,6 +802,7 @@ bool mesh_kernel_supports(const FrameParams& P) {
 }
 
 int mesh_tiles(int n) { return (n + kTile - 1) / kTile; }
+int mesh_occ_words(int grid) { return occ_words(grid); }
 int mesh_screen_cells(int pixels) { return (pixels + kScreenCell - 1) / kScreenCell; }
 
 // P.records must hold this frame's records (launch_stage_records) before the masks are built.
@@ -733,6 +812,8 @@ void launch_mesh(const FrameParams& P, bool count, hipStream_t stream) {
   if (P.screen_masks != nullptr) {
     hipMemsetAsync(P.screen_masks, 0, (size_t)P.scx * P.scy * nwords * 8, stream);
     hipMemsetAsync(P.world_masks, 0, (size_t)P.grid_g * P.grid_g * P.grid_g * nwords * 8, stream);
+    hipMemsetAsync(P.world_occ, 0, (size_t)occ_words(P.grid_g) * sizeof(unsigned int), stream);
+    hipLaunchKernelGGL(rt_bin_occupancy, dim3((P.n + P.nsph + 255) / 256), dim3(256), 0, stream, P);
     hipLaunchKernelGGL(rt_bin_primary, dim3((ntiles + kMeshWaves - 1) / kMeshWaves, P.scy), block, 0, stream, P);
     hipLaunchKernelGGL(rt_bin_shadow, dim3((ntiles + kMeshWaves - 1) / kMeshWaves, P.grid_g / 4, P.grid_g / 4), block, 0, stream, P);
   }
