@@ -83,7 +83,8 @@ __device__ __forceinline__ Bound task_bound(const TriLane& T, f3 s0, f3 D0, floa
   const float w1 = norm1(w0), ew1 = 2.002f * eb * norm1(g);
   const float W0 = sg * detc(md, w0);
   const float EW = (dlen_max * ew1 + edd * (w1 + ew1)) * 1.0001f;
-  const float slackW = 4e-6f * (dlen_max + hh) * ((p1 + ep1) + (q1 + eq1) + T.c1);
+  const float slackW = 4e-6f * (dlen_max + hh) * (((p1 + ep1) + (q1 + eq1) + T.c1) +
+                                                  (norm1(b0) + 3.0f * eb + T.e1_1) * (T.e1_1 + T.e2_1));
   // A sample can only hit if det(A), det(A0), det(A1), det(A2) share one sign (t,u,v >= 0): cull when
   // neither the all-positive nor the all-negative combination is possible.  No condition on det(A): this
   // also settles rays that are nearly parallel to the triangle's plane, where det(A) changes sign.
@@ -144,7 +145,8 @@ __device__ __forceinline__ Bound light_bundle_bound(const TriLane& T, f3 light, 
   const float wj = norm1(cof(b0 - T.e1, g)) + 2.002f * eb * g1;      // >= |wb|_1, any point
   const float W0 = sg * detc(md, wL);
   const float EW = (ed1 * norm1(wL) + hh * wj + rnd * g1) * 1.0001f;
-  const float slackW = 4e-6f * (dlen_max + hh) * (pj + qj + T.c1);
+  const float slackW = 4e-6f * (dlen_max + hh) * ((pj + qj + T.c1) +
+                                                  (norm1(Lv) + norm1(b0) + 3.0f * eb + T.e1_1) * (T.e1_1 + T.e2_1));
   const bool can_pos = (A0 + EA > 0.0f) && (nA0 + E0 > -1e-18f) && (N1 + E1 > -1e-18f) && (N2 + E2 > -1e-18f);
   const bool can_neg = (A0 - EA < 0.0f) && (nA0 - E0 < 1e-18f) && (N1 - E1 < 1e-18f) && (N2 - E2 < 1e-18f);
   const bool cR = (fabsf(nA0) - E0) * dmin > hiD * (dlen_max * 1.000004f);   // |t d|^2 >= radius_sq everywhere
@@ -180,11 +182,13 @@ __device__ __forceinline__ Bound point_bound(f3 start, f3 dir, float hh, float d
   // the sample direction, so its range over the jitter box is centre +- hh |w|_1.  (Bounding the three
   // determinants separately, as cW below must when det(A) may change sign, ignores that they move together:
   // a ray skimming along a face passes its top edge at u+v = 1.03 for every sample, yet the three separate
-  // intervals overlap.)  slack: w is not formed the way the reference forms p, q and c, and the reference
-  // rounds u, v and u+v; both are a few 2^-24 of |d| (|p|+|q|+|c|).
+  // intervals overlap.)  slack: the reference rounds u, v and u+v (a few 2^-24 of |d| (|p|+|q|+|c|)), and w is not
+  // formed the way the reference forms p, q and c (a few 2^-24 of |d| (|b|+|e1|) (|e1|+|e2|), whatever cancels).
   const f3 w = cof(b - e1, e2 - e1);
   const float W0 = sg * detc(md, w), hw = hh * norm1(w);
-  const float slackW = 4e-6f * (dlen + hh) * (p1 + q1 + c1);
+  // second term: w is rounded like any product of (b - e1) and (e2 - e1) however small p, q and c come out
+  const float e1n = norm1(e1);
+  const float slackW = 4e-6f * (dlen + hh) * ((p1 + q1 + c1) + (norm1(b) + e1n) * (e1n + norm1(e2)));
   // sign consistency of det(A), det(A0), det(A1), det(A2) (see task_bound); det(A0) is exact here
   const bool can_pos = (D0 + Delta > 0.0f) && (nA0 > -1e-18f) && (N1 + hp > -1e-18f) && (N2 + hq > -1e-18f);
   const bool can_neg = (D0 - Delta < 0.0f) && (nA0 < 1e-18f) && (N1 - hp < 1e-18f) && (N2 - hq < 1e-18f);
