@@ -176,7 +176,8 @@ int rt_init(const rt_config* cfg, const float* vertices4, const float* normals4,
   if (n > 64 && hipMalloc(&c->d_records, (size_t)n * 8 * sizeof(float4)) != hipSuccess) {
     set_error("hipMalloc failed: %s", hipGetErrorString(hipGetLastError())); return fail(RT_E_NOMEM);
   }
-  if (n > 64 && !(cfg->flags & (RT_FLAG_NO_TILE_BINS | RT_FLAG_NO_CULL | RT_FLAG_GENERIC_KERNEL))) {
+  // candidate-tile masks: from 17 tiles on (with fewer, building and reading them costs more than the visits they save)
+  if (n > 16 * 64 && !(cfg->flags & (RT_FLAG_NO_TILE_BINS | RT_FLAG_NO_CULL | RT_FLAG_GENERIC_KERNEL))) {
     c->nwords = (mesh_tiles(n) + 63) / 64;
     c->scx = mesh_screen_cells(cfg->width); c->scy = mesh_screen_cells(cfg->height);
     const size_t g3 = (size_t)kWorldGrid * kWorldGrid * kWorldGrid;
