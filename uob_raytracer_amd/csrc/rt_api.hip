@@ -203,7 +203,7 @@ int rt_init(const rt_config* cfg, const float* vertices4, const float* normals4,
   }
   {   // wave kernel: lists of last frame's expensive jobs (sized for the smallest job, one 64-ray task)
     const int aa = cfg->aa_x * cfg->aa_y;
-    const int pt = (aa >= 1 && aa <= 64 && 64 % aa == 0) ? 64 / aa : 64;
+    const int pt = (aa >= 1 && aa <= 64) ? 64 / aa : 64;
     const size_t jobs_max = (size_t)((cfg->width + pt - 1) / pt) * (size_t)(c->owned_rows > 0 ? c->owned_rows : 1);
     c->heavy_cap = (int)(jobs_max / 8 > 64 ? jobs_max / 8 : 64);
     if (hipMemset(c->d_jobctr, 0, (2 * kJobHeads + 2) * kJobHeadStride * sizeof(unsigned int)) != hipSuccess) {
@@ -257,15 +257,16 @@ static void fill_params(const rt_ctx* c, const float rot[12], const float cam[3]
   P->job_counter = c->d_jobctr + kJobHeadStride;      // [HeavyState 0 | queue heads | HeavyState 1], one line each
   {   // wave kernel: a job is a run of job_tasks 64-ray tasks (job_tasks * 64/aa pixels) of one row
     const int aa = g.aa_x * g.aa_y;
-    const bool pow2 = aa >= 1 && aa <= 64 && 64 % aa == 0;
-    // Job size: 64 pixels, halved while the queue would hold fewer than ~16 jobs per resident wave (jobs differ
+    const bool wave_aa = aa >= 1 && aa <= 64;
+    // Job size: up to 64 pixels, halved while the queue would hold fewer than ~16 jobs per resident wave (jobs differ
     // 10x in cost, but every hand-out stalls its wave for microseconds; measured with last frame's expensive jobs
     // going first: 4096 and 2048 rows -> 64 px, 1024 and 512 rows -> 32 px), but not below 16 pixels.
-    const int pt = pow2 ? 64 / aa : 64;
+    const int pt = wave_aa ? 64 / aa : 64;              // pixels per 64-ray task
+    P->aa_magic = wave_aa ? (65536 + aa - 1) / aa : 65536;
     const long waves = (long)c->cus * (g.band_count > 1 ? 4 : 5) * 4;
-    int jt = pow2 ? aa : 1;
-    while (jt > 1 && (jt / 2) * pt >= 16 && (long)((g.width + jt * pt - 1) / (jt * pt)) * c->owned_rows < 16 * waves) jt /= 2;
-    if (const char* e = getenv("UOB_RT_JOB_TASKS")) { const int v = atoi(e); if (pow2 && v >= 1 && v <= aa && aa % v == 0) jt = v; }
+    int jt = wave_aa ? 64 / pt : 1;                      // tasks of a 64-pixel job (aa for the power-of-two grids)
+    while (jt > 1 && ((jt + 1) / 2) * pt >= 16 && (long)((g.width + jt * pt - 1) / (jt * pt)) * c->owned_rows < 16 * waves) jt = (jt + 1) / 2;
+    if (const char* e = getenv("UOB_RT_JOB_TASKS")) { const int v = atoi(e); if (wave_aa && v >= 1 && v * pt <= 64) jt = v; }
     P->job_tasks = jt;
     const int job_pixels = jt * pt;
     P->nseg = (g.width + job_pixels - 1) / job_pixels;

@@ -279,8 +279,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
 
   const LdsScene S = lds_scene(lds, n, st);
   const int aa = P.aa_x * P.aa_y;                                     // a power of two <= 64 (supports())
-  const int la = __builtin_ctz(aa);
-  const int PT = 64 >> la;                                            // pixels per task
+  const int PT = 64 / aa;                                             // pixels per task (lanes >= PT * aa idle)
   const int GP = PT < kRngPixels ? PT : kRngPixels;                   // pixels per RNG group
   const f3 light = mk(P.light[0], P.light[1], P.light[2]);
   const float hbox = P.spread / 2.f;                                  // |crush()| <= range/2, :51
@@ -379,10 +378,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
   for (int k = 0; k < P.job_tasks; ++k) {
     const int lnA = opaque(lane);
     // ---- phase 1: 64 primary rays, lnA = (pixel, AA sample) -----------------------------------------
-    const int pj = k * PT + (lnA >> la);       // pixel of this lnA within the 64-pixel job
-    const int a = lnA & (aa - 1);              // AA sample index dy*rx+dx, kernels.cl:395
+    const int pA = (lnA * P.aa_magic) >> 16;   // lnA / aa
+    const int pj = k * PT + pA;                // pixel of this lnA within the job
+    const int a = lnA - pA * aa;               // AA sample index dy*rx+dx, kernels.cl:395
     const int x = x0 + pj;
-    const bool valid = x < P.W;
+    const bool valid = x < P.W && pA < PT;
     Ray ray = primary_ray(P, x, y, a % P.aa_x, a / P.aa_x);
     bool lit = false, secondary = false;
     const unsigned long long Kp = Kp_job;      // triangles a primary ray of this job may hit
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
     const int lnC = opaque(lane);
     // level 3 / brute force: the reference's sample test, one surface point at a time
     const int GL = GP * aa;                     // lanes per RNG group
-    for (int g = 0; g * GL < 64 && work != 0ull; ++g) {
+    for (int g = 0; g * GP < PT && work != 0ull; ++g) {
       const unsigned long long gm = (work >> (g * GL)) & (GL == 64 ? ~0ull : ((1ull << GL) - 1ull));
       if (gm == 0ull) continue;
       // xorshift streams of the GP pixels of this group: lnC c -> (pixel c/3, component c%3), :319,:331
@@ -603,14 +603,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
     // sum the AA rays of each pixel in index order (final_color_total +=, :415-425); a ray without a
     // contribution adds +0, which leaves the running sum unchanged bit for bit
     f3 acc = mk(0.f, 0.f, 0.f);
-    const int first = (lnD >> la) << la;
+    const int first = ((lnD * P.aa_magic) >> 16) * aa;
     for (int r = 0; r < aa; ++r) {
       acc = acc + mk(shfl(contrib.x, first + r), shfl(contrib.y, first + r), shfl(contrib.z, first + r));
     }
     // pixel pj's sum lives in lanes [pj*aa, pj*aa+aa); hand it to output lnD (k*PT + pj)
     {
       const int rel = lnD - k * PT;
-      const int srcl = (rel >= 0 && rel < PT) ? (rel << la) : 0;
+      const int srcl = (rel >= 0 && rel < PT) ? rel * aa : 0;
       const f3 v = mk(shfl(acc.x, srcl), shfl(acc.y, srcl), shfl(acc.z, srcl));
       if (rel >= 0 && rel < PT) outc = v;
     }
@@ -656,7 +656,7 @@ template __global__ void rt_draw_wave<true, false, false, 32>(const FrameParams)
 
 bool wave_kernel_supports(const FrameParams& P) {
   const int aa = P.aa_x * P.aa_y;
-  return P.S >= 1 && P.S <= 64 && aa >= 1 && aa <= 64 && (64 % aa) == 0 && P.n >= 1 && P.n <= 64 && P.n_shadow >= 1 &&
+  return P.S >= 1 && P.S <= 64 && aa >= 1 && aa <= 64 && P.n >= 1 && P.n <= 64 && P.n_shadow >= 1 &&
          P.spread >= 0.0f;
 }
 
