@@ -26,6 +26,9 @@ CASES = {
     "wave_s64_aa8x8_48": dict(width=48, height=48, aa_x=8, aa_y=8, shadow_samples=64),
     "wave_s64_aa4x2_ragged_100x37": dict(width=100, height=37, aa_x=4, aa_y=2, shadow_samples=64),
     "wave_s64_hard_shadow": dict(width=128, height=128, aa_x=2, aa_y=1, shadow_samples=64, light_spread=0.0),
+    # more than 64 shadow samples: passes of 64 sample lanes
+    "wave_s100_aa2x2": dict(width=96, height=64, shadow_samples=100),
+    "wave_s129_aa3x1_spread": dict(width=64, height=48, aa_x=3, aa_y=1, shadow_samples=129, light_spread=0.3),
     "wave_s64_bands": dict(width=128, height=120, aa_x=4, aa_y=2, shadow_samples=64, band_rows=8, band_index=1, band_count=3),
 }
 

@@ -42,7 +42,7 @@ def one_case(seed):
     else:
         scene = _random_scene(rng, int(rng.integers(2, 38)), box=bool(rng.integers(0, 2)))
     aa = [(1, 1), (2, 1), (2, 2), (4, 2), (4, 4), (8, 8), (3, 3), (3, 2), (5, 1), (7, 9), (6, 6)][int(rng.integers(0, 11))]
-    S = int(rng.choice([1, 2, 3, 8, 9, 10, 16, 33, 64]))
+    S = int(rng.choice([1, 2, 3, 8, 9, 10, 16, 33, 64, 65, 100, 200]))
     W, H = int(rng.integers(40, 200)), int(rng.integers(30, 140))
     bc = int(rng.choice([1, 1, 2, 3]))
     kw = dict(width=W, height=H, aa_x=aa[0], aa_y=aa[1], shadow_samples=S,

@@ -379,7 +379,7 @@ int rt_count_executed(rt_ctx* c, const float rot[12], const float cam[3], const 
   fill_params(c, rot, cam, light, focal, &P);
   const bool generic = (c->cfg.flags & RT_FLAG_GENERIC_KERNEL) != 0;
   const bool mesh = !generic && !wave_kernel_supports(P) && !(c->cfg.flags & RT_FLAG_NO_CULL) && mesh_kernel_supports(P);
-  if (generic || (!wave_kernel_supports(P) && !mesh)) {
+  if (generic || (!wave_kernel_supports(P) && !mesh) || (!mesh && P.S > 64)) {
     set_error("rt_count_executed: this configuration runs on the generic kernel, whose executed work is rt_count_work");
     return RT_E_UNSUPPORTED;
   }

@@ -239,7 +239,8 @@ __host__ __device__ constexpr int wave_fixed_lds_float4() {
   return kLdsRecords * STRIDE + STRIDE / 4 + 4 * STRIDE + kWavesPerBlock * wave_lds_bytes(CULL) / 16;
 }
 
-template <bool CULL, bool COUNT, bool PROF = false, int STRIDE = 0>
+// MULTI: more than 64 shadow samples per surface point, worked off in passes of 64 sample lanes
+template <bool CULL, bool COUNT, bool PROF = false, int STRIDE = 0, bool MULTI = false>
 // 5 waves per SIMD (<= 96 VGPRs, 36 B/lane of scratch spills): the kernel is bound by instruction issue
 // latency at low occupancy, 5 waves measured 11.3 ms vs 12.4 ms unconstrained (4 waves) and 11.5 ms at 6
 #ifndef RT_MIN_WAVES
@@ -285,7 +286,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
   const float hbox = P.spread / 2.f;                                  // |crush()| <= range/2, :51
   const unsigned long long tri_lanes = ns == 64 ? ~0ull : ((1ull << ns) - 1ull);
   const int NS = P.S;                                                 // shadow samples = sample lanes, <= 64
-  const unsigned long long active = NS == 64 ? ~0ull : ((1ull << NS) - 1ull);
+  const int n_pass = MULTI ? (NS + 63) >> 6 : 1;                      // passes of 64 sample lanes
+  const unsigned long long active = NS >= 64 ? ~0ull : ((1ull << NS) - 1ull);     // sample lanes of a full pass
 
   // triangle lane i < ns holds shadow-casting triangle i: resident in registers in the brute-force build,
   // re-read from LDS once per task by level 1 in the culled build (registers are what limits occupancy)
@@ -533,14 +535,23 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
     for (int g = 0; g * GP < PT && work != 0ull; ++g) {
       const unsigned long long gm = (work >> (g * GL)) & (GL == 64 ? ~0ull : ((1ull << GL) - 1ull));
       if (gm == 0ull) continue;
+      for (int pass = 0; pass < n_pass; ++pass) {
+      const int first_s = pass << 6;                                   // first sample of this pass
+      const int cnt_s = NS - first_s < 64 ? NS - first_s : 64;         // samples in it
+      const unsigned long long act = (!MULTI || cnt_s == 64) ? active : ((1ull << cnt_s) - 1ull);
       // xorshift streams of the GP pixels of this group: lnC c -> (pixel c/3, component c%3), :319,:331
       if (lnC < 3 * GP) {
         const int pp = lnC / 3, comp = lnC % 3;
-        const int gid = pixel_global_id(P, x0 + k * PT + g * GP + pp, y);
-        const uint32_t seed = comp == 0 ? (uint32_t)gid : (uint32_t)((float)gid * (comp == 1 ? 91.0f : 19.0f));
-        uint32_t s = xorshift(seed);
         uint32_t* dst = L.rng + pp * kRngStride + comp;
-        for (int it = 0; it < NS; ++it) { s = xorshift(s); dst[it * 4] = s; }
+        uint32_t s;
+        if (!MULTI || pass == 0) {
+          const int gid = pixel_global_id(P, x0 + k * PT + g * GP + pp, y);
+          const uint32_t seed = comp == 0 ? (uint32_t)gid : (uint32_t)((float)gid * (comp == 1 ? 91.0f : 19.0f));
+          s = xorshift(seed);
+        } else {
+          s = dst[63 * 4];                                               // the stream goes on where the last pass left it
+        }
+        for (int it = 0; it < cnt_s; ++it) { s = xorshift(s); dst[it * 4] = s; }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -549,7 +560,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
       for (int pp = 0; pp < GP; ++pp) {
         unsigned long long pm = (gm >> (pp * aa)) & (aa == 64 ? ~0ull : ((1ull << aa) - 1ull));
         if (pm == 0ull) continue;
-        const uint32_t* src = L.rng + pp * kRngStride + lnC * 4;     // lnC = sample index
+        const uint32_t* src = L.rng + pp * kRngStride + lnC * 4;     // lnC = sample index within the pass
         const f3 jit = mk(crush1(src[0], P.spread), crush1(src[1], P.spread), crush1(src[2], P.spread));
         const int base = g * GL + pp * aa;
         while (pm != 0ull) {
@@ -563,15 +574,18 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
             const unsigned long long n2 = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(need >> 32), j2) << 32) |
                                           (unsigned)__builtin_amdgcn_readlane((int)need, j2);
             const Count2 c2 = wave_unshadowed_pair<COUNT>(P, SC, L, lnC, j, j2, K, n1 | n2, (sphmask >> j) & 1ull,
-                                                          (sphmask >> j2) & 1ull, jit, active, xw);
-            if (lnC == j2) unshadowed = c2.b;
-            if (lnC == j) unshadowed = c2.a;
+                                                          (sphmask >> j2) & 1ull, jit, act, xw);
+            const int before = (MULTI && pass > 0) ? unshadowed : 0;     // j2 may be j again: add once
+            if (lnC == j2) unshadowed = before + c2.b;
+            if (lnC == j) unshadowed = before + c2.a;
           } else {
-            const int cnt = wave_unshadowed_all<COUNT>(P, T, L, lnC, ns, j, jit, active, xw);
-            if (lnC == j) unshadowed = cnt;
+            const int cnt = wave_unshadowed_all<COUNT>(P, T, L, lnC, ns, j, jit, act, xw);
+            if (lnC == j) unshadowed = (MULTI && pass > 0 ? unshadowed : 0) + cnt;
           }
         }
       }
+      if (MULTI) __builtin_amdgcn_wave_barrier();      // the next pass rewrites the scratch
+      }                                                 // passes
       __builtin_amdgcn_wave_barrier();          // scratch is rewritten by the next group
       RT_STAMP(5)                           // 5: level 3 sample tests
     }
@@ -653,10 +667,12 @@ template __global__ void rt_draw_wave<false, true>(const FrameParams);
 template __global__ void rt_draw_wave<true, true>(const FrameParams);
 template __global__ void rt_draw_wave<true, false, true>(const FrameParams);
 template __global__ void rt_draw_wave<true, false, false, 32>(const FrameParams);
+template __global__ void rt_draw_wave<true, false, false, 0, true>(const FrameParams);
+template __global__ void rt_draw_wave<false, false, false, 0, true>(const FrameParams);
 
 bool wave_kernel_supports(const FrameParams& P) {
   const int aa = P.aa_x * P.aa_y;
-  return P.S >= 1 && P.S <= 64 && aa >= 1 && aa <= 64 && P.n >= 1 && P.n <= 64 && P.n_shadow >= 1 &&
+  return P.S >= 1 && P.S <= 4096 && aa >= 1 && aa <= 64 && P.n >= 1 && P.n <= 64 && P.n_shadow >= 1 &&
          P.spread >= 0.0f;
 }
 
@@ -700,6 +716,9 @@ void launch_wave(const FrameParams& P, bool cull, bool count, hipStream_t stream
   if (count) {
     if (cull) hipLaunchKernelGGL((rt_draw_wave<true, true>), grid, block, lds_bytes, stream, P);
     else hipLaunchKernelGGL((rt_draw_wave<false, true>), grid, block, lds_bytes, stream, P);
+  } else if (P.S > 64) {
+    if (cull) hipLaunchKernelGGL((rt_draw_wave<true, false, false, 0, true>), grid, block, lds_bytes, stream, P);
+    else hipLaunchKernelGGL((rt_draw_wave<false, false, false, 0, true>), grid, block, lds_bytes, stream, P);
   } else {
     if (cull && P.n <= 32) hipLaunchKernelGGL((rt_draw_wave<true, false, false, 32>), grid, block, 0, stream, P);
     else if (cull) hipLaunchKernelGGL((rt_draw_wave<true, false>), grid, block, lds_bytes, stream, P);
