@@ -241,8 +241,8 @@ __host__ __device__ constexpr int wave_fixed_lds_float4() {
 
 // MULTI: more than 64 shadow samples per surface point, worked off in passes of 64 sample lanes
 template <bool CULL, bool COUNT, bool PROF = false, int STRIDE = 0, bool MULTI = false>
-// 5 waves per SIMD (<= 96 VGPRs, 36 B/lane of scratch spills): the kernel is bound by instruction issue
-// latency at low occupancy, 5 waves measured 11.3 ms vs 12.4 ms unconstrained (4 waves) and 11.5 ms at 6
+// 5 waves per SIMD (<= 96 VGPRs; what spills is written once per wave, outside the loops): the kernel is bound by
+// instruction issue and needs the waves — 5 per SIMD measured 3.76 ms against 4.10 ms at 4 (128 VGPRs)
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 5
 #endif
