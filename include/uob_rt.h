@@ -8,7 +8,12 @@
  *
  * Conventions: every function returns RT_OK (0) or a negative RT_E_* code; the message for the last
  * failure on the calling thread is available from rt_last_error().  A context is not thread-safe
- * (the reference has one host thread and one in-order queue, skeleton.cpp:388).
+ * (the reference has one host thread and one in-order queue, skeleton.cpp:388), and its frames run one at a
+ * time: a frame enqueued on another stream first waits for the context's previous frame.
+ * State a context carries from frame to frame: the wave kernel hands out the row segments that were expensive
+ * in the context's PREVIOUS frame first (scheduling only — no pixel depends on it; RT_FLAG_PLAIN_ORDER
+ * switches it off).  Tuning knobs are read ONCE, in rt_init, from the environment (UOB_RT_JOB_TASKS,
+ * UOB_RT_HEAVY_FACTOR4, UOB_RT_FULL_GRID: see DESIGN.md 4.1); nothing reads the environment afterwards.
  */
 #ifndef UOB_RT_H
 #define UOB_RT_H
@@ -19,8 +24,9 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 1
+#define RT_ABI_VERSION 2
 #define RT_MAX_SPHERES 4
+#define RT_MAX_DEVICES 8
 
 enum {
   RT_OK = 0,
@@ -56,14 +62,25 @@ typedef struct rt_config {
   int32_t band_rows, band_index, band_count;
   int32_t device;               /* HIP device ordinal; -1 = current device                            */
   int32_t flags;                /* RT_FLAG_*                                                           */
+  /* Several GPUs inside ONE context (one host thread, one stream per device — SURVEY.md 8(b) "Threading"):
+   * with num_devices > 1 the rows this context owns are split into interleaved bands of device_band_rows
+   * rows over devices[0..num_devices-1] (the same ordinal may be listed more than once), every device renders
+   * its bands on its own stream, and rt_render / rt_render_device deliver the assembled frame exactly as a
+   * single device would (bit-identical).  num_devices <= 1: `device` alone.  Needs band_count == 1.        */
+  int32_t num_devices;
+  int32_t devices[RT_MAX_DEVICES];
+  int32_t device_band_rows;     /* 0 = 32                                                              */
 } rt_config;
 
-#define RT_FLAG_FAST_MATH 1u    /* allow FMA contraction + v_rcp/v_rsq: NOT bit-exact */
 #define RT_FLAG_GENERIC_KERNEL 2u   /* always use the one-thread-per-pixel kernel (A/B and parity tests)  */
 #define RT_FLAG_NO_CULL 4u          /* wave kernel: test every triangle for every surface point (no interval
                                        culling); output is bit-identical either way                        */
 #define RT_FLAG_NO_TILE_BINS 8u     /* mesh kernel (n > 64): visit every 64-triangle tile instead of the per-frame
                                        candidate-tile masks; output is bit-identical either way                */
+#define RT_FLAG_PLAIN_ORDER 16u     /* wave kernel: hand the jobs out in plain order every frame (no "last frame's
+                                       expensive jobs first"): the context then carries no state from frame to frame */
+#define RT_FLAG_STAGED_GATHER 32u   /* several devices: every device renders into its own stripe and the bands are
+                                       copied to the destination, also for devices that could write it directly   */
 
 typedef struct rt_ctx rt_ctx;
 
@@ -126,6 +143,16 @@ int rt_count_executed(rt_ctx* ctx, const float rot[12], const float cam[3], cons
  * measured with hipEvents on the launch stream (synchronises that stream).                          */
 int rt_last_kernel_ms(rt_ctx* ctx, float* out_ms);
 
+/* Diagnostic: run the device functions of the path on caller-supplied rays (host arrays), one lane per ray,
+ * against the context's scene and sphere table — the function-level golden vectors of the reference are checked
+ * through this entry (tests/test_gpu_functions.py).  rays6 = nray x (start.xyz, direction.xyz).
+ *   RT_TRACE_IN_SHADOW   : in_shadow (kernels.cl:243-311) with radius_sq[nray]  -> out_tri[k] = 0 / 1
+ *   RT_TRACE_CLOSEST_HIT : single_ray_intersections (kernels.cl:168-241) -> out_tri[k] = -1 / -2 / triangle,
+ *                          out10[10k..] = intersect.xyz, normal.xyz, colour.xyzw (zero on a miss)          */
+enum { RT_TRACE_IN_SHADOW = 0, RT_TRACE_CLOSEST_HIT = 1 };
+int rt_debug_trace_rays(rt_ctx* ctx, int32_t what, const float* rays6, const float* radius_sq, int64_t nray,
+                        int32_t* out_tri, float* out10);
+
 /* On-device self test of the exact-reciprocal building block (rt_math.h rcp_newton): sweeps all 2^32
  * FP32 patterns and compares v_rcp_f32 + 1/2 Newton steps with the correctly rounded 1.0f/x.
  * out[0],out[1] = mismatches (1-step, 2-step) for 2^-100 <= |x| <= 2^100; out[2],out[3] = mismatches for
@@ -149,6 +176,12 @@ int rt_scene_cornell_box(rt_triangle* out, int32_t cap);
  * (-0.4,1.15,-0.7), colour blue (0,0.2,0.4,0.5); normals are those of the un-negated triangle.
  * Returns the triangle count (may exceed cap; only cap are written) or a negative error.             */
 int rt_scene_load_obj(const char* path, rt_triangle* out, int32_t cap);
+/* load_obj with the constants of Loader.cpp:20,42,48-52 as arguments: color[4] (w = material: >0 diffuse,
+ * 0 mirror, <0 glass), scale, and translate[3] applied after the negation (v' = -(scale*v) + translate).
+ * NULL color / translate = the reference's (0,0.2,0.4,0.5) / (-0.4,1.15,-0.7); rt_scene_load_obj(path,...) ==
+ * rt_scene_load_obj_ex(path, NULL, 1.5f, NULL, ...).                                                          */
+int rt_scene_load_obj_ex(const char* path, const float color[4], float scale, const float translate[3],
+                         rt_triangle* out, int32_t cap);
 /* ComputeNormal (TestModelH.h:26-35): normal = normalize(cross(v2-v0, v1-v0)), w = 1.               */
 void rt_triangle_compute_normal(rt_triangle* t);
 /* AoS -> the three packed float4 arrays (skeleton.cpp:474-484).                                      */

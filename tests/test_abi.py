@@ -31,14 +31,16 @@ def test_every_declared_symbol_is_exported():
 
 def test_struct_layouts_match_the_header(tmp_path):
     prog = tmp_path / "sz.c"
-    prog.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "uob_rt.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n",'
+    prog.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "uob_rt.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                     'sizeof(rt_config),sizeof(rt_sphere),sizeof(rt_work),sizeof(rt_triangle),'
-                    'offsetof(rt_config,spheres),offsetof(rt_config,band_rows));return 0;}\n')
+                    'offsetof(rt_config,spheres),offsetof(rt_config,band_rows),offsetof(rt_config,devices),'
+                    'offsetof(rt_config,device_band_rows));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
     assert [int(x) for x in out] == [C.sizeof(abi.RtConfig), C.sizeof(abi.RtSphere), C.sizeof(abi.RtWork),
-                                     C.sizeof(abi.RtTriangle), abi.RtConfig.spheres.offset, abi.RtConfig.band_rows.offset]
+                                     C.sizeof(abi.RtTriangle), abi.RtConfig.spheres.offset, abi.RtConfig.band_rows.offset,
+                                     abi.RtConfig.devices.offset, abi.RtConfig.device_band_rows.offset]
 
 
 def test_default_config_is_the_reference_constants():
@@ -61,7 +63,8 @@ def _init(cfg, scene):
 
 @pytest.mark.parametrize("kw", [dict(width=0), dict(aa_x=0), dict(shadow_samples=0), dict(max_bounces=-1),
                                 dict(band_index=2, band_count=2, band_rows=4), dict(width=8192, height=8192),
-                                dict(light_spread=-1.0), dict(flags=abi.RT_FLAG_FAST_MATH)])
+                                dict(light_spread=-1.0), dict(flags=1), dict(devices=(0, 0), band_rows=8, band_count=2),
+                                dict(device_band_rows=-1)])
 def test_invalid_configurations_are_rejected_before_touching_the_device(kw, scene):
     rc, msg = _init(abi.make_config(**kw), scene)
     assert rc in (abi.RT_E_INVALID, abi.RT_E_UNSUPPORTED) and msg
@@ -71,7 +74,7 @@ def test_scene_coordinate_bound(scene):
     big = rt.Scene(scene.aos.copy())
     big.aos[0, 0, 0] = 3.0e6
     rc, msg = _init(abi.make_config(), big)
-    assert rc == abi.RT_E_INVALID and "2^20" in msg
+    assert rc == abi.RT_E_INVALID and "2^16" in msg
     nan = rt.Scene(scene.aos.copy())
     nan.aos[3, 1, 2] = np.nan
     assert _init(abi.make_config(), nan)[0] == abi.RT_E_INVALID

@@ -1,0 +1,57 @@
+"""-m gpu: FUNCTION-level parity.  The device forms of in_shadow (kernels.cl:243-311) and
+single_ray_intersections (:168-241), run on caller rays through the C ABI (rt_debug_trace_rays), against the
+20 000-ray golden vectors produced by the REAL reference functions (tests/golden/function_vectors.npz, made by
+tests/golden/make_golden.py from Source/kernels.cl compiled for x86-64).  Tolerance: 0."""
+import os
+
+import numpy as np
+import pytest
+
+from uob_raytracer_amd import abi, meshgen, runtime as rt
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def vectors():
+    return np.load(os.path.join(G, "function_vectors.npz"))
+
+
+def test_in_shadow_against_reference_vectors(scene, vectors):
+    tr = rt.RayTracer(abi.make_config(width=64, height=64), scene)       # reference sphere table
+    got = tr.trace_in_shadow(vectors["rays"], vectors["radius_sq"])
+    tr.close()
+    assert np.array_equal(got, vectors["in_shadow"])
+    assert 0.05 < got.mean() < 0.95
+
+
+def test_closest_hit_against_reference_vectors(scene, vectors):
+    tr = rt.RayTracer(abi.make_config(width=64, height=64), scene)
+    tri, out = tr.trace_closest_hit(vectors["rays_unit"])
+    tr.close()
+    assert np.array_equal(tri, vectors["hit_tri"])
+    hit = tri != -1
+    assert np.array_equal(out[hit].view(np.uint32), vectors["hit_out"][hit].view(np.uint32))
+    assert set(np.unique(tri)) >= {-2, 0}
+
+
+@pytest.mark.parametrize("n_lon,n_lat", [(10, 8), (40, 30)])       # one LDS stage / HBM-resident records
+def test_functions_on_a_mesh_against_the_oracle(n_lon, n_lat, scene, oracle, vectors, tmp_path):
+    """The same entry on box + OBJ mesh (beyond what the reference's local memory holds): oracle as the checker."""
+    path = str(tmp_path / "m.obj")
+    meshgen.write_sphere_obj(path, n_lon, n_lat)
+    both = scene + rt.Scene.load_obj(path)
+    cfg = abi.make_config(width=64, height=64)
+    v, n, c = both.packed()
+    tr = rt.RayTracer(cfg, both)
+    rays, r2 = vectors["rays"][:4000], vectors["radius_sq"][:4000]
+    assert np.array_equal(tr.trace_in_shadow(rays, r2), oracle.in_shadow(cfg, v, c, rays, r2))
+    tri, out = tr.trace_closest_hit(vectors["rays_unit"][:4000])
+    o_tri, o_out = oracle.closest_hit(cfg, v, n, c, vectors["rays_unit"][:4000])
+    tr.close()
+    assert np.array_equal(tri, o_tri)
+    hit = tri != -1
+    assert np.array_equal(out[hit].view(np.uint32), o_out[hit].view(np.uint32))
+    assert (tri >= 26).any()                                           # some rays hit the mesh

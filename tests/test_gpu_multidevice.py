@@ -1,0 +1,89 @@
+"""-m gpu: several devices inside ONE context (rt_config.devices, SURVEY.md 8(b) "Threading"): the frame is split
+into interleaved bands over the listed devices, each renders on its own stream, the copy engines deliver the
+bands — the assembled frame must equal the single-device frame bit for bit, through rt_render (host buffer) and
+rt_render_device (device buffer; devices that hold the destination write it directly unless
+RT_FLAG_STAGED_GATHER).  A one-GPU box lists its device several times; every code path except the physical
+link is the same."""
+import numpy as np
+import pytest
+
+from conftest import focal_for
+from uob_raytracer_amd import abi, meshgen, runtime as rt
+
+pytestmark = pytest.mark.gpu
+
+ROT_CAM_LIGHT = [(0.0, 0.0, [0.0, 0.0, -3.2], [0.0, -0.5, -0.7]), (0.3, -0.1, [0.2, 0.1, -2.9], [-0.3, -0.5, -0.6])]
+
+
+def _single(kw, scene, pose):
+    yaw, pitch, cam, light = pose
+    cfg = abi.make_config(**kw)
+    tr = rt.RayTracer(cfg, scene)
+    out = tr.render(rt.rotation_matrix(yaw, pitch), cam, light, focal_for(cfg), want_rgb=True)
+    work = tr.count_work(rt.rotation_matrix(yaw, pitch), cam, light, focal_for(cfg))
+    tr.close()
+    return out, work
+
+
+@pytest.mark.parametrize("devices,dbr", [((0, 0), 32), ((0, 0, 0), 8), ((0, 0, 0, 0), 16), ((0,) * 8, 0)])
+@pytest.mark.parametrize("kw", [
+    dict(width=256, height=256, aa_x=4, aa_y=2, shadow_samples=64),
+    dict(width=200, height=173, shadow_samples=10),                      # ragged: 173 rows
+    dict(width=96, height=20, aa_x=3, aa_y=3, shadow_samples=5),          # fewer bands than devices; generic kernel
+])
+def test_host_frame_equals_single_device(devices, dbr, kw, scene):
+    for pose in ROT_CAM_LIGHT:
+        (argb, rgb), work = _single(kw, scene, pose)
+        cfg = abi.make_config(devices=devices, device_band_rows=dbr, **kw)
+        tr = rt.RayTracer(cfg, scene)
+        yaw, pitch, cam, light = pose
+        rot = rt.rotation_matrix(yaw, pitch)
+        a, f = tr.render(rot, cam, light, focal_for(cfg), want_rgb=True)
+        assert np.array_equal(a, argb)
+        assert np.array_equal(f.view(np.uint32), rgb.view(np.uint32))
+        assert tr.count_work(rot, cam, light, focal_for(cfg)) == work
+        assert tr.last_kernel_ms() > 0.0
+        tr.close()
+
+
+@pytest.mark.parametrize("flags", [0, abi.RT_FLAG_STAGED_GATHER])
+@pytest.mark.parametrize("devices,dbr", [((0, 0), 32), ((0, 0, 0), 8)])
+def test_device_frame_equals_single_device(devices, dbr, flags, scene):
+    import torch
+    kw = dict(width=320, height=203, aa_x=2, aa_y=2, shadow_samples=64)
+    for pose in ROT_CAM_LIGHT:
+        (argb, rgb), _ = _single(kw, scene, pose)
+        cfg = abi.make_config(devices=devices, device_band_rows=dbr, flags=flags, **kw)
+        tr = rt.RayTracer(cfg, scene)
+        yaw, pitch, cam, light = pose
+        buf = torch.full((203, 320), 0x55, dtype=torch.int32, device="cuda")
+        tap = torch.zeros((203, 320, 4), dtype=torch.float32, device="cuda")
+        for _ in range(3):          # frames in sequence: scheduling state, event reuse
+            tr.render_device(rt.rotation_matrix(yaw, pitch), cam, light, focal_for(cfg), buf.data_ptr(), tap.data_ptr(),
+                             torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(buf.cpu().numpy().view(np.uint32), argb)
+        assert np.array_equal(tap.cpu().numpy().view(np.uint32), rgb.view(np.uint32))
+        assert tr.last_kernel_ms() > 0.0
+        tr.close()
+
+
+def test_mesh_scene_over_three_devices(scene, tmp_path):
+    path = str(tmp_path / "m.obj")
+    meshgen.write_sphere_obj(path, 60, 40)                               # 4 680 triangles: tiled kernel with tile masks
+    both = scene + rt.Scene.load_obj(path)
+    kw = dict(width=160, height=131, aa_x=2, aa_y=1, shadow_samples=4)
+    pose = ROT_CAM_LIGHT[0]
+    (argb, rgb), work = _single(kw, both, pose)
+    cfg = abi.make_config(devices=(0, 0, 0), device_band_rows=16, **kw)
+    tr = rt.RayTracer(cfg, both)
+    yaw, pitch, cam, light = pose
+    a, f = tr.render(rt.rotation_matrix(yaw, pitch), cam, light, focal_for(cfg), want_rgb=True)
+    tr.close()
+    assert np.array_equal(a, argb) and np.array_equal(f.view(np.uint32), rgb.view(np.uint32))
+
+
+def test_unknown_device_is_rejected(scene):
+    with pytest.raises(rt.RtError) as e:
+        rt.RayTracer(abi.make_config(width=64, height=64, devices=(0, 99)), scene)
+    assert e.value.code == abi.RT_E_INVALID

@@ -41,12 +41,17 @@ def test_putpixel_and_saveimage(tmp_path):
 
 
 @pytest.mark.gpu
-def test_main_loop_binary_matches_python_path(tmp_path, scene):
+@pytest.mark.parametrize("extra", [[], ["--devices", "0,0,0"]])
+def test_main_loop_binary_matches_the_oracle(extra, tmp_path, scene, oracle):
+    """The C++ application loop (main / update / offload_rendering of skeleton.cpp over the C ABI) after six animated
+    frames with scripted key presses: its saved frame against the CPU ORACLE's render of the state that an
+    independent float32 replay of update() (skeleton.cpp:282-361) arrives at — also with the frame split over
+    three device entries inside the context."""
     from uob_raytracer_amd import abi, runtime as rt
     exe = os.path.join(ROOT, "uob_raytracer_amd", "uob_raytracer")
     out = str(tmp_path / "shot.bmp")
     keys = ["left", "i", "k", "up"]
-    res = subprocess.run([exe, "--size", "128", "--frames", "6", "--keys", " ".join(keys), "--out", out],
+    res = subprocess.run([exe, "--size", "128", "--frames", "6", "--keys", " ".join(keys), "--out", out] + extra,
                          check=True, capture_output=True, text=True)
     assert "Triangles Length size 26" in res.stdout and res.stdout.count("Frame Rate:") == 6
     # replay update() (skeleton.cpp:282-361) in float32 / double exactly as the C++ does
@@ -70,9 +75,10 @@ def test_main_loop_binary_matches_python_path(tmp_path, scene):
             if key == "i": cz = f32(f64(cz) + 0.1)
             if key == "k": cx = f32(f64(cx) + 0.1)
     cfg = abi.make_config(width=128, height=128)
-    tr = rt.RayTracer(cfg, scene)
-    want = tr.render(rt.rotation_matrix(float(yaw), float(pitch)), [cx, 0.0, cz], [lx, -0.5, -0.7], 1100.0 * 128 / 1024 * 2)
-    tr.close()
+    v, n, c = scene.packed()
+    want, _ = oracle.render(cfg, v, n, c, rt.rotation_matrix(float(yaw), float(pitch)), [cx, 0.0, cz], [lx, -0.5, -0.7],
+                            1100.0 * 128 / 1024 * 2)
     got = read_bmp(out)
-    assert np.array_equal(got, want)
+    assert np.array_equal(got.ravel(), want)
+    assert (got != 0xFF000000).mean() > 0.5
     assert ("light_position.x %.9g" % lx) in res.stdout

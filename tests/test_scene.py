@@ -71,6 +71,27 @@ def test_obj_loader_hardening_beyond_the_reference(tmp_path):
         assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32)), faces
 
 
+def test_obj_loader_material_and_placement():
+    """rt_scene_load_obj_ex: the constants Loader.cpp hard-codes (:20 colour, :42 scale, :48-52
+    translation) as arguments.  Defaults == the reference's loader bit for bit; other values against a float32
+    restatement of the same three lines on the reference loader's own output of the fixture mesh."""
+    path = os.path.join(G, "mesh_small.obj")
+    ref = np.load(os.path.join(G, "mesh_small_aos.npy"))                    # produced by the reference's load_obj
+    same = rt.Scene.load_obj(path, color=(0.0, 0.2, 0.4, 0.5), scale=1.5, translate=(-0.4, 1.15, -0.7)).aos
+    assert np.array_equal(same.view(np.uint32), ref.view(np.uint32))
+    f32 = np.float32
+    col, sc, mv = (0.9, 0.8, 0.7, 0.0), f32(0.75), np.array([0.2, 0.9, -0.3], f32)
+    got = rt.Scene.load_obj(path, color=col, scale=float(sc), translate=mv).aos
+    assert (got[:, 4, :] == np.array(col, f32)).all()
+    # undo the reference's placement exactly (v' = -(1.5 v) + t is inverted through the raw OBJ coordinates)
+    raw = np.array([[float(t) for t in line.split()[1:4]] for line in open(path) if line.startswith("v ")], f32)
+    faces = [[int(t) - 1 for t in line.split()[1:4]] for line in open(path) if line.startswith("f ")]
+    want = np.stack([(f32(-1.0) * (sc * raw[f])) + mv for f in faces])      # [n,3,3]
+    assert np.array_equal(got[:, :3, :3].view(np.uint32), want.view(np.uint32))
+    # normals: those of the un-negated, scaled triangle (Loader.cpp:46) — unchanged by a positive scale up to rounding
+    assert np.nanmax(np.abs(got[:, 3, :3] - ref[:, 3, :3])) < 1e-5          # (the fixture holds one degenerate triangle: NaN)
+
+
 def test_scene_concatenation_like_reference_main(scene):
     """skeleton.cpp:102-103: triangles.insert(end, bunny...)"""
     mesh = rt.Scene.load_obj(os.path.join(G, "mesh_small.obj"))

@@ -1,13 +1,16 @@
 """ctypes mirror of include/uob_rt.h (struct layouts and constants only; loads nothing)."""
 import ctypes as C
 
-RT_ABI_VERSION = 1
+RT_ABI_VERSION = 2
 RT_MAX_SPHERES = 4
+RT_MAX_DEVICES = 8
 RT_OK, RT_E_INVALID, RT_E_DEVICE, RT_E_NOMEM, RT_E_IO, RT_E_UNSUPPORTED = 0, -1, -2, -3, -4, -5
-RT_FLAG_FAST_MATH = 1
 RT_FLAG_GENERIC_KERNEL = 2
 RT_FLAG_NO_CULL = 4
 RT_FLAG_NO_TILE_BINS = 8
+RT_FLAG_PLAIN_ORDER = 16
+RT_FLAG_STAGED_GATHER = 32
+RT_TRACE_IN_SHADOW, RT_TRACE_CLOSEST_HIT = 0, 1
 
 
 class RtSphere(C.Structure):
@@ -23,6 +26,7 @@ class RtConfig(C.Structure):
         ("spheres", RtSphere * RT_MAX_SPHERES),
         ("band_rows", C.c_int32), ("band_index", C.c_int32), ("band_count", C.c_int32),
         ("device", C.c_int32), ("flags", C.c_int32),
+        ("num_devices", C.c_int32), ("devices", C.c_int32 * RT_MAX_DEVICES), ("device_band_rows", C.c_int32),
     ]
 
 
@@ -48,7 +52,7 @@ REFERENCE_SPHERES = (
 
 def make_config(width=1024, height=1024, aa_x=2, aa_y=2, shadow_samples=10, light_spread=0.05,
                 max_bounces=10, spheres=REFERENCE_SPHERES, band_rows=0, band_index=0, band_count=1,
-                device=-1, flags=0):
+                device=-1, flags=0, devices=(), device_band_rows=0):
     """Reference constants by default (kernels.cl:7-17, :316-317, :343); same as rt_config_default()."""
     cfg = RtConfig()
     cfg.width, cfg.height, cfg.aa_x, cfg.aa_y = width, height, aa_x, aa_y
@@ -64,4 +68,11 @@ def make_config(width=1024, height=1024, aa_x=2, aa_y=2, shadow_samples=10, ligh
     cfg.band_rows = band_rows if band_rows > 0 else height
     cfg.band_index, cfg.band_count = band_index, band_count
     cfg.device, cfg.flags = device, flags
+    devices = tuple(devices or ())
+    if len(devices) > RT_MAX_DEVICES:
+        raise ValueError("at most %d devices" % RT_MAX_DEVICES)
+    cfg.num_devices = len(devices)
+    for i, d in enumerate(devices):
+        cfg.devices[i] = d
+    cfg.device_band_rows = device_band_rows
     return cfg

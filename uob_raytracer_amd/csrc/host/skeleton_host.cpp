@@ -7,6 +7,8 @@
 // camera controls from an optional script of key names ("up down left right i o k j", :312-352).
 //
 //   uob_raytracer [--size N] [--frames K] [--aa X Y] [--shadows S] [--keys "left left i"] [--out file.bmp]
+//                 [--obj mesh.obj]            append load_obj(mesh.obj) to the box, as skeleton.cpp:102-103 does
+//                 [--gpus N | --devices a,b,..]  render every frame on several GPUs inside the one context
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -84,6 +86,7 @@ bool update() {                                                // :282-361
 int main(int argc, char* argv[]) {
   int frames = 10;
   const char* out = "screenshot.bmp";
+  const char* obj = nullptr;
   rt_config cfg;
   rt_config_default(&cfg);
   for (int i = 1; i < argc; ++i) {
@@ -94,6 +97,15 @@ int main(int argc, char* argv[]) {
     else if (a == "--shadows" && i + 1 < argc) cfg.shadow_samples = atoi(argv[++i]);
     else if (a == "--keys" && i + 1 < argc) { istringstream in(argv[++i]); string k; while (in >> k) g_keys.push_back(k); }
     else if (a == "--out" && i + 1 < argc) out = argv[++i];
+    else if (a == "--obj" && i + 1 < argc) obj = argv[++i];
+    else if (a == "--gpus" && i + 1 < argc) {
+      cfg.num_devices = atoi(argv[++i]);
+      if (cfg.num_devices < 1 || cfg.num_devices > RT_MAX_DEVICES) { fprintf(stderr, "--gpus must be in [1,%d]\n", RT_MAX_DEVICES); return 2; }
+      for (int d = 0; d < cfg.num_devices; ++d) cfg.devices[d] = d;
+    } else if (a == "--devices" && i + 1 < argc) {
+      istringstream in(argv[++i]); string tok; cfg.num_devices = 0;
+      while (getline(in, tok, ',') && cfg.num_devices < RT_MAX_DEVICES) cfg.devices[cfg.num_devices++] = atoi(tok.c_str());
+    }
     else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
   }
   cfg.width = SCREEN_WIDTH; cfg.height = SCREEN_HEIGHT; cfg.band_rows = SCREEN_HEIGHT;
@@ -104,6 +116,12 @@ int main(int argc, char* argv[]) {
   const int n = rt_scene_cornell_box(triangles.data(), 64);                   // LoadTestModel, :101
   if (n < 0) die("rt_scene_cornell_box");
   triangles.resize(n);
+  if (obj) {                                                                   // load_obj + insert, :102-103
+    const int m = rt_scene_load_obj(obj, nullptr, 0);
+    if (m < 0) die("rt_scene_load_obj");
+    triangles.resize((size_t)n + m);
+    if (rt_scene_load_obj(obj, triangles.data() + n, m) != m) die("rt_scene_load_obj");
+  }
   printf("Triangles Length size %lu\n", triangles.size());                    // :104
   opencl_initialise(cfg);                                                      // :106
 

@@ -5,6 +5,14 @@
 // rt_render  replaces offload_rendering  (Source/skeleton.cpp:146-182): per-frame arguments, the kernel
 //            launch that stands where clEnqueueNDRangeKernel(draw) stood (:172), blocking readback (:179).
 // There is no CPU fallback: without a HIP device every device entry point fails with RT_E_DEVICE.
+//
+// Several GPUs in one context (rt_config.num_devices > 1; SURVEY.md 8(b) "Threading", section 5): the context
+// owns one child context per listed device, each with its own stream, scene copy and stripe; a frame is launched
+// on all of them from the one host thread, and the bands are delivered by the copy engines — straight into the
+// caller's host framebuffer over each device's own PCIe link (rt_render), or into the caller's device buffer
+// over the direct xGMI link to that device (rt_render_device).  A gather to one root over point-to-point links
+// IS N-1 independent peer copies; they occupy no compute unit, so they run beside the next frame's persistent
+// grid.  (The one-process-per-GPU flow of bench.py gathers with RCCL through torch.distributed instead.)
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -34,7 +42,9 @@ void set_error(const char* fmt, ...) {
 void launch_generic(const FrameParams& P, bool count, hipStream_t stream);
 bool generic_needs_records(int n);
 void launch_stage_records(const FrameParams& P, hipStream_t stream);
-void launch_mesh(const FrameParams& P, bool count, hipStream_t stream);
+void launch_trace_rays(const FrameParams& P, int what, const float* d_rays, const float* d_r2, long nray, int* d_tri,
+                       float* d_out10, hipStream_t stream);
+void launch_mesh(const FrameParams& P, bool count, bool prof, hipStream_t stream);
 bool mesh_kernel_supports(const FrameParams& P);
 int mesh_tiles(int n);
 int mesh_occ_words(int grid);
@@ -42,6 +52,7 @@ int mesh_screen_cells(int pixels);
 void launch_wave(const FrameParams& P, bool cull, bool count, hipStream_t stream);
 void launch_wave_prof(const FrameParams& P, hipStream_t stream);
 bool wave_kernel_supports(const FrameParams& P);
+int wave_blocks_per_cu(bool leave_room);
 
 }  // namespace uobrt
 
@@ -58,13 +69,23 @@ using namespace uobrt;
 
 constexpr int kWorldGrid = 32;       // world cells per axis of the mesh kernel's shadow-ray tile masks
 
+// Tuning knobs, read from the environment ONCE per context (rt_init); 0 / false = the built-in choice
+struct Tuning {
+  int job_tasks = 0;          // UOB_RT_JOB_TASKS: 64-ray tasks per job of the wave kernel
+  int heavy_factor4 = 8;      // UOB_RT_HEAVY_FACTOR4: a job is expensive above this / 4 times the average cost
+  bool plain_order = false;   // RT_FLAG_PLAIN_ORDER or UOB_RT_PLAIN_ORDER
+  bool full_grid = false;     // UOB_RT_FULL_GRID: a rank of a multi-GPU job fills every wave slot too
+  bool phase_profile = false; // UOB_RT_PHASE_PROFILE: rt_count_executed returns s_memtime shares per phase
+};
+
 struct rt_ctx {
   rt_config cfg;
+  Tuning tune;
   int device = 0;
   int n = 0, n_shadow = 0;
   int owned_rows = 0;
   float4 *d_verts = nullptr, *d_normals = nullptr, *d_colors = nullptr;
-  uint32_t* d_argb = nullptr;      // internal framebuffer for rt_render
+  uint32_t* d_argb = nullptr;      // internal framebuffer (stripe) for rt_render
   float4* d_rgb = nullptr;         // lazily allocated float tap
   unsigned long long* d_counters = nullptr;
   unsigned int* d_jobctr = nullptr; // wave kernel's job queue heads
@@ -82,6 +103,12 @@ struct rt_ctx {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
+  hipStream_t last_stream = nullptr;
+  // several devices: one child context per entry of cfg.devices (then this context owns no device memory)
+  std::vector<rt_ctx*> kids;
+  hipEvent_t ev_go = nullptr;       // parent: "the caller's stream has reached this frame"
+  hipEvent_t ev_done = nullptr;     // child: "this device's bands have been delivered"
+  bool peer_ok = true;              // child: its device can copy 2-D into the destination device directly
 };
 
 static int validate_config(const rt_config* c) {
@@ -97,19 +124,43 @@ static int validate_config(const rt_config* c) {
   if (c->band_count < 1 || c->band_index < 0 || c->band_index >= c->band_count || c->band_rows < 1) {
     set_error("band partition invalid (rows=%d index=%d count=%d)", c->band_rows, c->band_index, c->band_count); return RT_E_INVALID;
   }
-  if (!(c->light_spread >= 0.0f) || !(c->light_spread <= 1048576.0f)) { set_error("light_spread must be in [0, 2^20]"); return RT_E_INVALID; }
+  if (!(c->light_spread >= 0.0f) || !(c->light_spread <= kMaxCoordinate)) { set_error("light_spread must be in [0, 2^16]"); return RT_E_INVALID; }
   for (int i = 0; i < c->num_spheres; ++i) {
     const rt_sphere& s = c->spheres[i];
     for (int k = 0; k < 3; ++k)
-      if (!(fabsf(s.center[k]) <= 1048576.0f)) { set_error("sphere %d: |centre| must be finite and <= 2^20", i); return RT_E_INVALID; }
-    if (!(fabsf(s.radius_sq) <= 1099511627776.0f)) { set_error("sphere %d: radius_sq must be finite and <= 2^40", i); return RT_E_INVALID; }
+      if (!(fabsf(s.center[k]) <= kMaxCoordinate)) { set_error("sphere %d: |centre| must be finite and <= 2^16", i); return RT_E_INVALID; }
+    if (!(fabsf(s.radius_sq) <= kMaxCoordinate * kMaxCoordinate)) { set_error("sphere %d: radius_sq must be finite and <= 2^32", i); return RT_E_INVALID; }
   }
   if ((double)c->width * c->height > 16777216.0) {
     // global_id = y*W+x is formed in FP32 by the reference (kernels.cl:380): exact only up to 2^24
     set_error("width*height must not exceed 2^24 (the reference's FP32 pixel id)"); return RT_E_INVALID;
   }
+  if (c->flags & 1) { set_error("flag bit 0 (the former RT_FLAG_FAST_MATH) is not defined in ABI %d", RT_ABI_VERSION); return RT_E_UNSUPPORTED; }
+  if (c->num_devices < 0 || c->num_devices > RT_MAX_DEVICES || c->device_band_rows < 0) {
+    set_error("num_devices must be in [0,%d] and device_band_rows >= 0", RT_MAX_DEVICES); return RT_E_INVALID;
+  }
+  if (c->num_devices > 1 && c->band_count != 1) {
+    set_error("several devices in one context need the whole frame (band_count == 1)"); return RT_E_UNSUPPORTED;
+  }
   return RT_OK;
 }
+
+static Tuning read_tuning(const rt_config& cfg) {
+  Tuning t;
+  if (const char* e = getenv("UOB_RT_JOB_TASKS")) t.job_tasks = atoi(e);
+  if (const char* e = getenv("UOB_RT_HEAVY_FACTOR4")) { const int v = atoi(e); if (v >= 1 && v <= 4096) t.heavy_factor4 = v; }
+  t.plain_order = (cfg.flags & RT_FLAG_PLAIN_ORDER) != 0 || getenv("UOB_RT_PLAIN_ORDER") != nullptr;
+  t.full_grid = getenv("UOB_RT_FULL_GRID") != nullptr;
+  t.phase_profile = getenv("UOB_RT_PHASE_PROFILE") != nullptr;
+  return t;
+}
+
+// Keeps the calling thread's current device unchanged across an API call (the caller may be a torch process)
+struct DeviceGuard {
+  int prev = -1;
+  DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+  ~DeviceGuard() { if (prev >= 0) hipSetDevice(prev); }
+};
 
 extern "C" {
 
@@ -129,6 +180,7 @@ void rt_config_default(rt_config* cfg) {
   cfg->spheres[0] = glass; cfg->spheres[1] = mirror;
   cfg->band_rows = cfg->height; cfg->band_index = 0; cfg->band_count = 1;
   cfg->device = -1; cfg->flags = 0;
+  cfg->num_devices = 0; cfg->device_band_rows = 0;
 }
 
 int32_t rt_config_owned_rows(const rt_config* c) {
@@ -138,6 +190,53 @@ int32_t rt_config_owned_rows(const rt_config* c) {
   return rows;
 }
 
+static int init_parent(const rt_config* cfg, const float* vertices4, const float* normals4, const float* colors4,
+                       int32_t n, rt_ctx** out_ctx) {
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (ndev < 1) { set_error("no HIP device present"); return RT_E_DEVICE; }
+  for (int d = 0; d < cfg->num_devices; ++d)
+    if (cfg->devices[d] < 0 || cfg->devices[d] >= ndev) {
+      set_error("devices[%d] = %d, but %d HIP device(s) are present", d, cfg->devices[d], ndev); return RT_E_INVALID;
+    }
+  rt_ctx* p = new (std::nothrow) rt_ctx();
+  if (!p) { set_error("out of host memory"); return RT_E_NOMEM; }
+  p->cfg = *cfg;
+  p->device = cfg->devices[0];
+  p->n = n;
+  p->owned_rows = rt_config_owned_rows(cfg);
+  const int dbr = cfg->device_band_rows > 0 ? cfg->device_band_rows : 32;
+  p->cfg.device_band_rows = dbr;
+  for (int d = 0; d < cfg->num_devices; ++d) {
+    rt_config kc = *cfg;
+    kc.num_devices = 0; kc.device = cfg->devices[d];
+    kc.band_rows = dbr; kc.band_index = d; kc.band_count = cfg->num_devices;
+    rt_ctx* k = nullptr;
+    const int rc = rt_init(&kc, vertices4, normals4, colors4, n, &k);
+    if (rc != RT_OK) { rt_destroy(p); return rc; }
+    p->kids.push_back(k);
+    if (hipSetDevice(k->device) != hipSuccess || hipEventCreateWithFlags(&k->ev_done, hipEventDisableTiming) != hipSuccess) {
+      set_error("event creation failed on device %d", k->device); rt_destroy(p); return RT_E_DEVICE;
+    }
+    if (k->device != p->device) {           // let the copy engines of this device write the root's memory directly
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, k->device, p->device) == hipSuccess && can) {
+        const hipError_t e = hipDeviceEnablePeerAccess(p->device, 0);
+        k->peer_ok = (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled);
+      } else {
+        k->peer_ok = false;
+      }
+      (void)hipGetLastError();
+    }
+  }
+  if (hipSetDevice(p->device) != hipSuccess || hipEventCreateWithFlags(&p->ev_go, hipEventDisableTiming) != hipSuccess ||
+      hipStreamCreate(&p->stream) != hipSuccess || hipEventCreate(&p->ev0) != hipSuccess || hipEventCreate(&p->ev1) != hipSuccess) {
+    set_error("stream/event creation failed on device %d", p->device); rt_destroy(p); return RT_E_DEVICE;
+  }
+  *out_ctx = p;
+  return RT_OK;
+}
+
 int rt_init(const rt_config* cfg, const float* vertices4, const float* normals4, const float* colors4,
             int32_t n, rt_ctx** out_ctx) {
   if (!out_ctx) { set_error("out_ctx is NULL"); return RT_E_INVALID; }
@@ -145,22 +244,27 @@ int rt_init(const rt_config* cfg, const float* vertices4, const float* normals4,
   int rc = validate_config(cfg);
   if (rc != RT_OK) return rc;
   if (n < 0 || (n > 0 && (!vertices4 || !normals4 || !colors4))) { set_error("scene arrays missing"); return RT_E_INVALID; }
-  // Coordinate bound: keeps every determinant of the intersection tests below 2^126, the range in which
-  // the v_rcp_f32 + Newton reciprocal equals IEEE division bit for bit (rt_math.h rcp_exact).
+  // Coordinate bound: the range over which the exact culls are verified and which keeps every
+  // determinant of the intersection tests below 2^126, where the v_rcp_f32 + Newton reciprocal equals IEEE
+  // division bit for bit (rt_math.h rcp_exact).
   for (size_t k = 0; k < (size_t)n * 12; ++k) {
-    if ((k & 3) != 3 && !(fabsf(vertices4[k]) <= 1048576.0f)) {
-      set_error("vertex %zu: coordinates must be finite and |x| <= 2^20", k / 4); return RT_E_INVALID;
+    if ((k & 3) != 3 && !(fabsf(vertices4[k]) <= kMaxCoordinate)) {
+      set_error("vertex %zu: coordinates must be finite and |x| <= 2^16", k / 4); return RT_E_INVALID;
     }
   }
-  if (cfg->flags & RT_FLAG_FAST_MATH) { set_error("RT_FLAG_FAST_MATH is not built into this library"); return RT_E_UNSUPPORTED; }
   if (n > 4000000) { set_error("triangle list of %d exceeds the supported maximum of 4000000", n); return RT_E_UNSUPPORTED; }
+  DeviceGuard guard;
+  if (cfg->num_devices > 1) return init_parent(cfg, vertices4, normals4, colors4, n, out_ctx);
   int ndev = 0;
   HIP_TRY(hipGetDeviceCount(&ndev));
   if (ndev < 1) { set_error("no HIP device present"); return RT_E_DEVICE; }
   rt_ctx* c = new (std::nothrow) rt_ctx();
   if (!c) { set_error("out of host memory"); return RT_E_NOMEM; }
   c->cfg = *cfg;
-  if (cfg->device >= 0) { c->device = cfg->device; } else { hipGetDevice(&c->device); }
+  c->tune = read_tuning(*cfg);
+  if (cfg->num_devices == 1) c->device = cfg->devices[0];
+  else if (cfg->device >= 0) c->device = cfg->device;
+  else hipGetDevice(&c->device);
   auto fail = [&](int code) { rt_destroy(c); return code; };
   if (hipSetDevice(c->device) != hipSuccess) { set_error("hipSetDevice(%d) failed", c->device); return fail(RT_E_DEVICE); }
   c->n = n;
@@ -173,7 +277,7 @@ int rt_init(const rt_config* cfg, const float* vertices4, const float* normals4,
       hipMalloc(&c->d_counters, sizeof(rt_work)) != hipSuccess || hipMalloc(&c->d_jobctr, (2 * kJobHeads + 2) * kJobHeadStride * sizeof(unsigned int)) != hipSuccess) {
     set_error("hipMalloc failed: %s", hipGetErrorString(hipGetLastError())); return fail(RT_E_NOMEM);
   }
-  if (n > 64 && hipMalloc(&c->d_records, (size_t)n * 8 * sizeof(float4)) != hipSuccess) {
+  if (n > 64 && hipMalloc(&c->d_records, (size_t)n * kRecordsPerTriangle * sizeof(float4)) != hipSuccess) {
     set_error("hipMalloc failed: %s", hipGetErrorString(hipGetLastError())); return fail(RT_E_NOMEM);
   }
   // candidate-tile masks: from 17 tiles on (with fewer, building and reading them costs more than the visits they save)
@@ -209,7 +313,7 @@ int rt_init(const rt_config* cfg, const float* vertices4, const float* normals4,
     if (hipMemset(c->d_jobctr, 0, (2 * kJobHeads + 2) * kJobHeadStride * sizeof(unsigned int)) != hipSuccess) {
       set_error("hipMemset failed: %s", hipGetErrorString(hipGetLastError())); return fail(RT_E_DEVICE);
     }
-    if (n >= 1 && n <= 64) {
+    if (n >= 1 && n <= 64 && !c->tune.plain_order) {
       if (hipMalloc(&c->d_heavy[0], (size_t)c->heavy_cap * 4) != hipSuccess || hipMalloc(&c->d_heavy[1], (size_t)c->heavy_cap * 4) != hipSuccess ||
           hipMalloc(&c->d_heavy_flags, jobs_max * 4) != hipSuccess || hipMemset(c->d_heavy_flags, 0, jobs_max * 4) != hipSuccess) {
         set_error("hipMalloc failed: %s", hipGetErrorString(hipGetLastError())); return fail(RT_E_NOMEM);
@@ -231,6 +335,8 @@ int rt_init(const rt_config* cfg, const float* vertices4, const float* normals4,
   *out_ctx = c;
   return RT_OK;
 }
+
+}  // extern "C"
 
 static void fill_params(const rt_ctx* c, const float rot[12], const float cam[3], const float light[3], float focal,
                         FrameParams* P) {
@@ -263,10 +369,14 @@ static void fill_params(const rt_ctx* c, const float rot[12], const float cam[3]
     // going first: 4096 and 2048 rows -> 64 px, 1024 and 512 rows -> 32 px), but not below 16 pixels.
     const int pt = wave_aa ? 64 / aa : 64;              // pixels per 64-ray task
     P->aa_magic = wave_aa ? (65536 + aa - 1) / aa : 65536;
-    const long waves = (long)c->cus * (g.band_count > 1 ? 4 : 5) * 4;
+    // workgroups the chip holds at once; a rank of a multi-GPU job leaves one slot per CU free (registers and LDS
+    // for a workgroup of a collective's kernels), so that the gather of the previous frame can run beside it
+    const int per_cu = wave_blocks_per_cu(g.band_count > 1 && !c->tune.full_grid);
+    P->wave_blocks = c->cus * per_cu;
+    const long waves = (long)P->wave_blocks * 4;
     int jt = wave_aa ? 64 / pt : 1;                      // tasks of a 64-pixel job (aa for the power-of-two grids)
     while (jt > 1 && ((jt + 1) / 2) * pt >= 16 && (long)((g.width + jt * pt - 1) / (jt * pt)) * c->owned_rows < 16 * waves) jt = (jt + 1) / 2;
-    if (const char* e = getenv("UOB_RT_JOB_TASKS")) { const int v = atoi(e); if (wave_aa && v >= 1 && v * pt <= 64) jt = v; }
+    if (wave_aa && c->tune.job_tasks >= 1 && c->tune.job_tasks * pt <= 64) jt = c->tune.job_tasks;
     P->job_tasks = jt;
     const int job_pixels = jt * pt;
     P->nseg = (g.width + job_pixels - 1) / job_pixels;
@@ -276,70 +386,166 @@ static void fill_params(const rt_ctx* c, const float rot[12], const float cam[3]
     P->screen_masks = c->d_screen_masks; P->world_masks = c->d_world_masks; P->world_occ = c->d_world_occ;
     P->nwords = c->nwords; P->scx = c->scx; P->scy = c->scy; P->grid_g = kWorldGrid;
     // World grid: a cube over the scene box, grown so that every shadow-ray start point X + 1e-4 (light - X)
-    // of a surface point X in the box (kernels.cl:324) stays inside, rounding included.
-    float ext = 0.0f, dmax = 0.0f, amax = 0.0f;
+    // of a surface point X in the box (kernels.cl:324) stays inside, rounding included; X itself is computed
+    // from the camera (X = cam + t dir, or v0 + u e1 + v e2), so its rounding scales with the camera's and the
+    // scene's coordinates.
+    float ext = 0.0f, dmax = 0.0f, amax = 0.0f, cmax = 0.0f;
     for (int k = 0; k < 3; ++k) {
       ext = fmaxf(ext, c->box_hi[k] - c->box_lo[k]);
       dmax = fmaxf(dmax, fmaxf(fabsf(light[k] - c->box_lo[k]), fabsf(light[k] - c->box_hi[k])));
       amax = fmaxf(amax, fmaxf(fabsf(c->box_lo[k]), fabsf(c->box_hi[k])));
+      cmax = fmaxf(cmax, fabsf(cam[k]));
     }
-    const float grow = 2e-4f * dmax + 1e-4f * (1.0f + amax) + 1e-3f * ext;
+    const float grow = 2e-4f * dmax + 1e-4f * (amax + cmax) + 1e-3f * ext + 1e-30f;
     for (int k = 0; k < 3; ++k) P->grid_lo[k] = c->box_lo[k] - grow;
     P->grid_cell = (ext + 2.0f * grow) / (float)kWorldGrid;
     P->grid_inv = 1.0f / P->grid_cell;
   }
 }
 
+// One frame of a single-device context into d_argb (packed rows, or global rows when out_global) on `stream`
 static int launch_frame(rt_ctx* c, const float rot[12], const float cam[3], const float light[3], float focal,
-                        uint32_t* d_argb, float4* d_rgb, hipStream_t stream) {
+                        uint32_t* d_argb, float4* d_rgb, hipStream_t stream, bool out_global = false) {
   if (!c || !rot || !cam || !light) { set_error("NULL argument"); return RT_E_INVALID; }
   for (int k = 0; k < 3; ++k)
-    if (!(fabsf(cam[k]) <= 1048576.0f) || !(fabsf(light[k]) <= 1048576.0f)) {
-      set_error("camera / light coordinates must be finite and <= 2^20"); return RT_E_INVALID;
+    if (!(fabsf(cam[k]) <= kMaxCoordinate) || !(fabsf(light[k]) <= kMaxCoordinate)) {
+      set_error("camera / light coordinates must be finite and <= 2^16"); return RT_E_INVALID;
     }
+  if (!(fabsf(focal) <= 1.0e9f)) { set_error("focal length must be finite and <= 1e9"); return RT_E_INVALID; }
+  for (int k = 0; k < 12; ++k)
+    if (!(fabsf(rot[k]) <= 4.0f)) { set_error("rotation matrix entries must be finite and <= 4"); return RT_E_INVALID; }
   if (c->owned_rows == 0) return RT_OK;
   FrameParams P;
   fill_params(c, rot, cam, light, focal, &P);
   P.out_argb = d_argb; P.out_rgb = d_rgb; P.counters = nullptr;
+  P.out_global = out_global ? 1 : 0;
   HIP_TRY(hipSetDevice(c->device));
+  // one frame of a context at a time: the queue heads, the expensive-job lists and the tile masks are shared
+  if (c->timed && stream != c->last_stream) HIP_TRY(hipStreamWaitEvent(stream, c->ev1, 0));
   HIP_TRY(hipEventRecord(c->ev0, stream));
   const bool wave_paths = !(c->cfg.flags & RT_FLAG_GENERIC_KERNEL);
   if (wave_paths && wave_kernel_supports(P)) {
     // last frame's expensive jobs first — where jobs are long enough (4+ tasks) for the extra look-up per
     // hand-out not to matter (measured: 1024^2 frames with 16-pixel jobs lose 12-18 % to it, larger ones gain 2-8 %)
-    if (c->d_heavy_flags && P.job_tasks >= 4 && !getenv("UOB_RT_PLAIN_ORDER")) {
+    if (c->d_heavy_flags && P.job_tasks >= 4) {
       const int prev = c->heavy_phase, cur = prev ^ 1;
       unsigned int* const st[2] = {c->d_jobctr, c->d_jobctr + (2 * kJobHeads + 1) * kJobHeadStride};
       P.heavy_prev = c->d_heavy[prev]; P.heavy_prev_state = st[prev];
       P.heavy_new = c->d_heavy[cur]; P.heavy_new_state = st[cur];
       P.heavy_flags = c->d_heavy_flags; P.heavy_gen = ++c->heavy_gen;
-      P.heavy_factor4 = 8;                                          // expensive = more than twice the average job
-      if (const char* e = getenv("UOB_RT_HEAVY_FACTOR4")) { const int v = atoi(e); if (v >= 1 && v <= 4096) P.heavy_factor4 = v; }
+      P.heavy_factor4 = c->tune.heavy_factor4;                      // expensive = more than twice the average job
       P.heavy_cap = P.njobs / 8 < c->heavy_cap ? P.njobs / 8 : c->heavy_cap;
       c->heavy_phase = cur;
     }
     launch_wave(P, !(c->cfg.flags & RT_FLAG_NO_CULL), false, stream);
   } else if (wave_paths && !(c->cfg.flags & RT_FLAG_NO_CULL) && mesh_kernel_supports(P)) {
     launch_stage_records(P, stream);        // per frame: the records hold camera-dependent terms
-    launch_mesh(P, false, stream);
+    launch_mesh(P, false, false, stream);
   } else {
     launch_generic(P, false, stream);
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(c->ev1, stream));
   c->timed = true;
+  c->last_stream = stream;
   return RT_OK;
 }
+
+// ---- several devices --------------------------------------------------------------------------------------
+// Child k of a parent with N children owns the bands k, k+N, ... of `dbr` rows; its stripe holds them packed.
+// Copy them to image order at `dst` (row pitch W elements of `elem` bytes) — one 2-D copy whose "rows" are whole
+// bands, plus the ragged last band if this child owns it.
+static int deliver_bands(rt_ctx* p, int k, const void* stripe, void* dst, size_t elem, hipMemcpyKind kind, hipStream_t stream) {
+  rt_ctx* c = p->kids[k];
+  const int N = (int)p->kids.size(), dbr = p->cfg.device_band_rows, W = p->cfg.width;
+  const size_t band_bytes = (size_t)dbr * W * elem;
+  const int full = c->owned_rows / dbr, rem = c->owned_rows % dbr;
+  char* const d0 = (char*)dst + (size_t)k * band_bytes;
+  if (full > 0) {
+    hipError_t e = hipErrorUnknown;
+    if (kind != hipMemcpyDeviceToDevice || c->peer_ok)
+      e = hipMemcpy2DAsync(d0, (size_t)N * band_bytes, stripe, band_bytes, band_bytes, (size_t)full, kind, stream);
+    if (e != hipSuccess && kind == hipMemcpyDeviceToDevice) {        // no peer mapping: band by band through the runtime
+      (void)hipGetLastError();
+      for (int b = 0; b < full; ++b)
+        HIP_TRY(hipMemcpyPeerAsync(d0 + (size_t)b * N * band_bytes, p->device, (const char*)stripe + (size_t)b * band_bytes,
+                                   c->device, band_bytes, stream));
+    } else if (e != hipSuccess) {
+      set_error("hipMemcpy2DAsync failed: %s", hipGetErrorString(e)); return RT_E_DEVICE;
+    }
+  }
+  if (rem > 0) {
+    const size_t bytes = (size_t)rem * W * elem;
+    char* const d1 = d0 + (size_t)full * N * band_bytes;
+    const char* const s1 = (const char*)stripe + (size_t)full * band_bytes;
+    if (kind == hipMemcpyDeviceToDevice && c->device != p->device) HIP_TRY(hipMemcpyPeerAsync(d1, p->device, s1, c->device, bytes, stream));
+    else HIP_TRY(hipMemcpyAsync(d1, s1, bytes, kind, stream));
+  }
+  return RT_OK;
+}
+
+static int parent_render(rt_ctx* p, const float rot[12], const float cam[3], const float light[3], float focal,
+                         uint32_t* host_argb, float* host_rgb, uint32_t* d_argb, float4* d_rgb, hipStream_t caller) {
+  const bool to_host = host_argb != nullptr;
+  const size_t W = (size_t)p->cfg.width;
+  if (!to_host) {                                     // the caller's earlier work on the destination comes first
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipEventRecord(p->ev0, caller));
+    HIP_TRY(hipEventRecord(p->ev_go, caller));
+  }
+  for (size_t k = 0; k < p->kids.size(); ++k) {
+    rt_ctx* c = p->kids[k];
+    if (c->owned_rows == 0) continue;
+    HIP_TRY(hipSetDevice(c->device));
+    const bool want_rgb = to_host ? host_rgb != nullptr : d_rgb != nullptr;
+    if (want_rgb && !c->d_rgb) HIP_TRY(hipMalloc(&c->d_rgb, (size_t)c->owned_rows * W * sizeof(float4)));
+    if (!to_host) HIP_TRY(hipStreamWaitEvent(c->stream, p->ev_go, 0));
+    // a device that holds the destination writes its rows there itself; the others render into their stripe
+    const bool direct = !to_host && c->device == p->device && !(p->cfg.flags & RT_FLAG_STAGED_GATHER);
+    int rc = direct ? launch_frame(c, rot, cam, light, focal, d_argb, d_rgb, c->stream, true)
+                    : launch_frame(c, rot, cam, light, focal, c->d_argb, want_rgb ? c->d_rgb : nullptr, c->stream);
+    if (rc != RT_OK) return rc;
+    if (!direct) {
+      const hipMemcpyKind kind = to_host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+      rc = deliver_bands(p, (int)k, c->d_argb, to_host ? (void*)host_argb : (void*)d_argb, 4, kind, c->stream);
+      if (rc == RT_OK && want_rgb)
+        rc = deliver_bands(p, (int)k, c->d_rgb, to_host ? (void*)host_rgb : (void*)d_rgb, sizeof(float4), kind, c->stream);
+      if (rc != RT_OK) return rc;
+    }
+    if (!to_host) HIP_TRY(hipEventRecord(c->ev_done, c->stream));
+  }
+  if (to_host) {
+    for (rt_ctx* c : p->kids) if (c->owned_rows) { HIP_TRY(hipSetDevice(c->device)); HIP_TRY(hipStreamSynchronize(c->stream)); }
+  } else {
+    HIP_TRY(hipSetDevice(p->device));
+    for (rt_ctx* c : p->kids) if (c->owned_rows) HIP_TRY(hipStreamWaitEvent(caller, c->ev_done, 0));
+    HIP_TRY(hipEventRecord(p->ev1, caller));
+    p->timed = true;
+  }
+  return RT_OK;
+}
+
+extern "C" {
 
 int rt_render_device(rt_ctx* c, const float rot[12], const float cam[3], const float light[3], float focal,
                      void* d_out_argb, void* d_out_rgb_f32, void* hip_stream) {
   if (!c || !d_out_argb) { set_error("NULL argument"); return RT_E_INVALID; }
+  DeviceGuard guard;
+  if (!c->kids.empty()) {
+    if (!rot || !cam || !light) { set_error("NULL argument"); return RT_E_INVALID; }
+    return parent_render(c, rot, cam, light, focal, nullptr, nullptr, (uint32_t*)d_out_argb, (float4*)d_out_rgb_f32, (hipStream_t)hip_stream);
+  }
   return launch_frame(c, rot, cam, light, focal, (uint32_t*)d_out_argb, (float4*)d_out_rgb_f32, (hipStream_t)hip_stream);
 }
 
 int rt_render(rt_ctx* c, const float rot[12], const float cam[3], const float light[3], float focal,
               uint32_t* out_argb, float* out_rgb_f32) {
   if (!c || !out_argb) { set_error("NULL argument"); return RT_E_INVALID; }
+  DeviceGuard guard;
+  if (!c->kids.empty()) {
+    if (!rot || !cam || !light) { set_error("NULL argument"); return RT_E_INVALID; }
+    return parent_render(c, rot, cam, light, focal, out_argb, out_rgb_f32, nullptr, nullptr, nullptr);
+  }
   const size_t px = (size_t)c->owned_rows * c->cfg.width;
   if (out_rgb_f32 && !c->d_rgb) {
     HIP_TRY(hipSetDevice(c->device));
@@ -358,6 +564,16 @@ int rt_render(rt_ctx* c, const float rot[12], const float cam[3], const float li
 int rt_count_work(rt_ctx* c, const float rot[12], const float cam[3], const float light[3], float focal, rt_work* out) {
   if (!c || !out || !rot || !cam || !light) { set_error("NULL argument"); return RT_E_INVALID; }
   memset(out, 0, sizeof *out);
+  DeviceGuard guard;
+  if (!c->kids.empty()) {
+    for (rt_ctx* k : c->kids) {
+      rt_work w;
+      const int rc = rt_count_work(k, rot, cam, light, focal, &w);
+      if (rc != RT_OK) return rc;
+      for (size_t q = 0; q < sizeof(rt_work) / 8; ++q) ((uint64_t*)out)[q] += ((const uint64_t*)&w)[q];
+    }
+    return RT_OK;
+  }
   if (c->owned_rows == 0) return RT_OK;
   FrameParams P;
   fill_params(c, rot, cam, light, focal, &P);
@@ -374,6 +590,16 @@ int rt_count_work(rt_ctx* c, const float rot[12], const float cam[3], const floa
 int rt_count_executed(rt_ctx* c, const float rot[12], const float cam[3], const float light[3], float focal, uint64_t out[8]) {
   if (!c || !out || !rot || !cam || !light) { set_error("NULL argument"); return RT_E_INVALID; }
   memset(out, 0, 8 * sizeof(uint64_t));
+  DeviceGuard guard;
+  if (!c->kids.empty()) {
+    for (rt_ctx* k : c->kids) {
+      uint64_t w[8];
+      const int rc = rt_count_executed(k, rot, cam, light, focal, w);
+      if (rc != RT_OK) return rc;
+      for (int q = 0; q < 8; ++q) out[q] += w[q];
+    }
+    return RT_OK;
+  }
   if (c->owned_rows == 0) return RT_OK;
   FrameParams P;
   fill_params(c, rot, cam, light, focal, &P);
@@ -385,9 +611,10 @@ int rt_count_executed(rt_ctx* c, const float rot[12], const float cam[3], const 
   }
   P.counters = c->d_counters;
   HIP_TRY(hipSetDevice(c->device));
+  if (c->timed) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev1, 0));
   HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(rt_work), c->stream));
-  if (mesh) { launch_stage_records(P, c->stream); launch_mesh(P, true, c->stream); }
-  else if (getenv("UOB_RT_PHASE_PROFILE")) launch_wave_prof(P, c->stream);   // diagnostic: s_memtime per phase
+  if (mesh) { launch_stage_records(P, c->stream); launch_mesh(P, true, c->tune.phase_profile, c->stream); }
+  else if (c->tune.phase_profile) launch_wave_prof(P, c->stream);   // diagnostic: s_memtime per phase
   else launch_wave(P, !(c->cfg.flags & RT_FLAG_NO_CULL), true, c->stream);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(out, c->d_counters, sizeof(rt_work), hipMemcpyDeviceToHost, c->stream));
@@ -395,9 +622,62 @@ int rt_count_executed(rt_ctx* c, const float rot[12], const float cam[3], const 
   return RT_OK;
 }
 
+int rt_debug_trace_rays(rt_ctx* c, int32_t what, const float* rays6, const float* radius_sq, int64_t nray,
+                        int32_t* out_tri, float* out10) {
+  if (!c || !rays6 || !out_tri || nray < 0) { set_error("NULL argument"); return RT_E_INVALID; }
+  if (what != RT_TRACE_IN_SHADOW && what != RT_TRACE_CLOSEST_HIT) { set_error("rt_debug_trace_rays: unknown mode %d", what); return RT_E_INVALID; }
+  if (what == RT_TRACE_IN_SHADOW && !radius_sq) { set_error("rt_debug_trace_rays: radius_sq missing"); return RT_E_INVALID; }
+  if (what == RT_TRACE_CLOSEST_HIT && !out10) { set_error("rt_debug_trace_rays: out10 missing"); return RT_E_INVALID; }
+  if (!c->kids.empty()) c = c->kids[0];
+  if (nray == 0) return RT_OK;
+  DeviceGuard guard;
+  HIP_TRY(hipSetDevice(c->device));
+  const float zero3[3] = {0.f, 0.f, 0.f}, ident[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+  FrameParams P;
+  fill_params(c, ident, zero3, zero3, 1.0f, &P);
+  float *d_rays = nullptr, *d_r2 = nullptr, *d_out = nullptr;
+  int* d_tri = nullptr;
+  int rc = RT_OK;
+  if (hipMalloc(&d_rays, (size_t)nray * 24) != hipSuccess || hipMalloc(&d_tri, (size_t)nray * 4) != hipSuccess ||
+      (radius_sq && hipMalloc(&d_r2, (size_t)nray * 4) != hipSuccess) || (out10 && hipMalloc(&d_out, (size_t)nray * 40) != hipSuccess)) {
+    set_error("hipMalloc failed: %s", hipGetErrorString(hipGetLastError())); rc = RT_E_NOMEM;
+  }
+  auto ok = [&](hipError_t e, const char* opn) {
+    if (rc == RT_OK && e != hipSuccess) { set_error("%s failed: %s", opn, hipGetErrorString(e)); rc = RT_E_DEVICE; }
+  };
+  if (rc == RT_OK) {
+    if (c->timed) ok(hipStreamWaitEvent(c->stream, c->ev1, 0), "hipStreamWaitEvent");
+    ok(hipMemcpyAsync(d_rays, rays6, (size_t)nray * 24, hipMemcpyHostToDevice, c->stream), "ray upload");
+    if (radius_sq) ok(hipMemcpyAsync(d_r2, radius_sq, (size_t)nray * 4, hipMemcpyHostToDevice, c->stream), "ray upload");
+    if (d_out) ok(hipMemsetAsync(d_out, 0, (size_t)nray * 40, c->stream), "hipMemsetAsync");
+    if (rc == RT_OK) {
+      if (generic_needs_records(c->n)) launch_stage_records(P, c->stream);
+      launch_trace_rays(P, what, d_rays, d_r2, (long)nray, d_tri, d_out, c->stream);
+      ok(hipGetLastError(), "trace kernel launch");
+    }
+    ok(hipMemcpyAsync(out_tri, d_tri, (size_t)nray * 4, hipMemcpyDeviceToHost, c->stream), "read-back");
+    if (out10 && what == RT_TRACE_CLOSEST_HIT) ok(hipMemcpyAsync(out10, d_out, (size_t)nray * 40, hipMemcpyDeviceToHost, c->stream), "read-back");
+    ok(hipStreamSynchronize(c->stream), "hipStreamSynchronize");
+  }
+  hipFree(d_rays); hipFree(d_r2); hipFree(d_out); hipFree(d_tri);
+  return rc;
+}
+
 int rt_last_kernel_ms(rt_ctx* c, float* out_ms) {
   if (!c || !out_ms) { set_error("NULL argument"); return RT_E_INVALID; }
+  DeviceGuard guard;
+  if (!c->kids.empty() && !c->timed) {      // after rt_render into host memory: the slowest device's kernel
+    float mx = -1.0f;
+    for (rt_ctx* k : c->kids) {
+      float ms = 0.0f;
+      if (k->timed && rt_last_kernel_ms(k, &ms) == RT_OK && ms > mx) mx = ms;
+    }
+    if (mx < 0.0f) { set_error("no frame has been rendered on this context"); return RT_E_INVALID; }
+    *out_ms = mx;
+    return RT_OK;
+  }
   if (!c->timed) { set_error("no frame has been rendered on this context"); return RT_E_INVALID; }
+  HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipEventSynchronize(c->ev1));
   HIP_TRY(hipEventElapsedTime(out_ms, c->ev0, c->ev1));
   return RT_OK;
@@ -405,10 +685,14 @@ int rt_last_kernel_ms(rt_ctx* c, float* out_ms) {
 
 void rt_destroy(rt_ctx* c) {
   if (!c) return;
+  DeviceGuard guard;
+  for (rt_ctx* k : c->kids) rt_destroy(k);
   hipSetDevice(c->device);
   if (c->stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); }
   if (c->ev0) hipEventDestroy(c->ev0);
   if (c->ev1) hipEventDestroy(c->ev1);
+  if (c->ev_go) hipEventDestroy(c->ev_go);
+  if (c->ev_done) hipEventDestroy(c->ev_done);
   hipFree(c->d_verts); hipFree(c->d_normals); hipFree(c->d_colors);
   hipFree(c->d_argb); hipFree(c->d_rgb); hipFree(c->d_counters); hipFree(c->d_records); hipFree(c->d_jobctr);
   hipFree(c->d_screen_masks); hipFree(c->d_world_masks); hipFree(c->d_world_occ);

@@ -14,6 +14,10 @@ constexpr int kJobHeadStride = 32;      // in 32-bit words: one 128-byte line pe
 // HeavyState, in 32-bit words: [0] entries in the list, [2..3] sum of all job costs (64-bit, s_memtime ticks),
 // [4] jobs counted
 constexpr int kHeavyStateWords = 8;
+// Largest |coordinate| rt_init / rt_render accept (vertices, sphere centres, camera, light, light_spread): the range
+// over which the exact culls are verified against the unculled paths (tools/fuzz_paths.py --wide)
+constexpr float kMaxCoordinate = 65536.0f;
+constexpr int kRecordsPerTriangle = 8;   // float4 records per triangle staged by stage_triangles (rt_trace.h)
 
 struct DevSphere {
   float cx, cy, cz, r2;
@@ -41,6 +45,9 @@ struct FrameParams {
   const float4* colors;   // float4[n], w = material flag
   uint32_t* out_argb;     // owned_rows * W ARGB8888 words
   float4* out_rgb;        // nullable: owned_rows * W pre-quantisation colours
+  int32_t out_global;     // 1: the output buffers are whole frames addressed by the GLOBAL row (a device of a
+                          // multi-device context writing its bands straight into the assembled frame); 0: packed rows
+  int32_t wave_blocks;    // wave kernel: workgroups the device holds at once (its persistent grid)
   unsigned long long* counters;  // nullable: rt_work, 8 x u64
   unsigned int* job_counter;   // wave kernel: kJobHeads queue heads, one per 128-B line (zeroed before each launch)
   int32_t njobs, nseg;    // wave kernel: jobs in total / per row

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void rt_draw_generic(const FrameParams P) {
     }
     const float inv = (float)(P.aa_x * P.aa_y);
     const f3 c = mk(total.x / inv, total.y / inv, total.z / inv);
-    const size_t o = (size_t)lr * P.W + x;
+    const size_t o = (size_t)(P.out_global ? y : lr) * P.W + x;
     if (!COUNT) {
       P.out_argb[o] = pack_argb(c);
       if (P.out_rgb) P.out_rgb[o] = make_float4(c.x, c.y, c.z, 1.0f);
@@ -113,7 +113,49 @@ template __global__ void rt_draw_generic<true, false>(const FrameParams);
 template __global__ void rt_draw_generic<false, true>(const FrameParams);
 template __global__ void rt_draw_generic<true, true>(const FrameParams);
 
+// Diagnostic (rt_debug_trace_rays): the device functions on caller rays, one lane per ray.
+//   what 0: in_shadow (kernels.cl:243-311)   what 1: single_ray_intersections (:168-241)
+template <bool BIG>
+__global__ __launch_bounds__(256) void rt_trace_rays(const FrameParams P, int what, const float* rays, const float* r2, long nray,
+                                                     int* out_tri, float* out10) {
+  extern __shared__ float4 lds_dyn[];
+  const float4* lds = BIG ? P.records : lds_dyn;
+  if (!BIG) {
+    stage_triangles(P, lds_dyn, threadIdx.x, 256);
+    __syncthreads();
+  }
+  const LdsScene S = lds_scene(lds, P.n);
+  Work wk;
+  for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < nray; k += (long)gridDim.x * 256) {
+    const f3 start = mk(rays[6 * k], rays[6 * k + 1], rays[6 * k + 2]), dir = mk(rays[6 * k + 3], rays[6 * k + 4], rays[6 * k + 5]);
+    if (what == 0) {
+      out_tri[k] = in_shadow<false>(S, P, start, dir, r2[k], wk) ? 1 : 0;
+    } else {
+      Ray ray;
+      ray.start = start; ray.dir = dir; ray.tri = -1; ray.medium = RT_AIR;
+      ray.col = make_float4(0.f, 0.f, 0.f, 1.0f);
+      ray.P = mk(0.f, 0.f, 0.f); ray.N = mk(0.f, 0.f, 0.f);
+      closest_hit<false>(S, P, ray, wk);
+      out_tri[k] = ray.tri;
+      if (ray.tri != -1) {
+        float* o = out10 + 10 * k;
+        o[0] = ray.P.x; o[1] = ray.P.y; o[2] = ray.P.z; o[3] = ray.N.x; o[4] = ray.N.y; o[5] = ray.N.z;
+        o[6] = ray.col.x; o[7] = ray.col.y; o[8] = ray.col.z; o[9] = ray.col.w;
+      }
+    }
+  }
+}
+
 bool generic_needs_records(int n) { return n > kLdsMaxTriangles; }
+
+// P.records must already hold the staged records when the mesh exceeds one LDS stage
+void launch_trace_rays(const FrameParams& P, int what, const float* d_rays, const float* d_r2, long nray, int* d_tri,
+                       float* d_out10, hipStream_t stream) {
+  const long blocks = (nray + 255) / 256;
+  const dim3 grid((unsigned)(blocks < 4096 ? (blocks > 0 ? blocks : 1) : 4096));
+  if (generic_needs_records(P.n)) hipLaunchKernelGGL((rt_trace_rays<true>), grid, dim3(256), 0, stream, P, what, d_rays, d_r2, nray, d_tri, d_out10);
+  else hipLaunchKernelGGL((rt_trace_rays<false>), grid, dim3(256), (size_t)P.n * kLdsRecords * sizeof(float4), stream, P, what, d_rays, d_r2, nray, d_tri, d_out10);
+}
 
 void launch_stage_records(const FrameParams& P, hipStream_t stream) {
   hipLaunchKernelGGL(rt_stage_records, dim3((P.n + 255) / 256), dim3(256), 0, stream, P);

@@ -789,7 +789,7 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
   if (!COUNT && !PROF && lr < P.owned_rows && x < P.W) {      // the counting pass has no framebuffer
     const float inv = (float)aa;
     const f3 c = mk(outc.x / inv, outc.y / inv, outc.z / inv);
-    const size_t o = (size_t)lr * P.W + x;
+    const size_t o = (size_t)(P.out_global ? band_global_row(lr, P.band_rows, P.band_index, P.band_count) : lr) * P.W + x;
     P.out_argb[o] = pack_argb(c);
     if (P.out_rgb) P.out_rgb[o] = make_float4(c.x, c.y, c.z, 1.0f);
   }
@@ -806,7 +806,7 @@ int mesh_occ_words(int grid) { return occ_words(grid); }
 int mesh_screen_cells(int pixels) { return (pixels + kScreenCell - 1) / kScreenCell; }
 
 // P.records must hold this frame's records (launch_stage_records) before the masks are built.
-void launch_mesh(const FrameParams& P, bool count, hipStream_t stream) {
+void launch_mesh(const FrameParams& P, bool count, bool prof, hipStream_t stream) {
   const dim3 block(64 * kMeshWaves);
   const int ntiles = mesh_tiles(P.n), nwords = (ntiles + 63) / 64;
   if (P.screen_masks != nullptr) {
@@ -819,7 +819,7 @@ void launch_mesh(const FrameParams& P, bool count, hipStream_t stream) {
   }
   const dim3 grid((P.W + 15) / 16, (P.owned_rows + 15) / 16);
   const size_t lds_bytes = kBatch * kSlot * sizeof(float4) + kMeshWaves * (size_t)mesh_wave_lds_bytes(P.S > kPointSamples || P.nsph > 0) + 2 * (size_t)nwords * 8;
-  if (count && getenv("UOB_RT_PHASE_PROFILE")) hipLaunchKernelGGL((rt_draw_mesh<false, true>), grid, block, lds_bytes, stream, P);
+  if (count && prof) hipLaunchKernelGGL((rt_draw_mesh<false, true>), grid, block, lds_bytes, stream, P);
   else if (count) hipLaunchKernelGGL((rt_draw_mesh<true>), grid, block, lds_bytes, stream, P);
   else hipLaunchKernelGGL((rt_draw_mesh<false>), grid, block, lds_bytes, stream, P);
 }

@@ -635,7 +635,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
   if (!COUNT && !PROF && lane < JP && x < P.W) {
     const float inv = (float)aa;
     const f3 c = mk(outc.x / inv, outc.y / inv, outc.z / inv);
-    const size_t o = (size_t)lr * P.W + x;
+    const size_t o = (size_t)(P.out_global ? y : lr) * P.W + x;
     P.out_argb[o] = pack_argb(c);
     if (P.out_rgb) P.out_rgb[o] = make_float4(c.x, c.y, c.z, 1.0f);
   }
@@ -681,17 +681,10 @@ static size_t wave_kernel_lds(const FrameParams& P, bool cull) {
          (size_t)P.n_shadow * 4 * sizeof(float4) + kWavesPerBlock * (size_t)wave_lds_bytes(cull);
 }
 
+int wave_blocks_per_cu(bool leave_room) { return leave_room ? RT_MIN_WAVES - 1 : RT_MIN_WAVES; }
+
 static dim3 wave_grid(const FrameParams& P) {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0;
-    hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-  }
-  // workgroups the chip holds at once; a rank of a multi-GPU job leaves one slot per CU free (registers and LDS
-  // for a workgroup of the collective's kernels), so that the gather of the previous frame can run beside it
-  const int per_cu = (P.band_count > 1 && !getenv("UOB_RT_FULL_GRID")) ? RT_MIN_WAVES - 1 : RT_MIN_WAVES;
-  const int resident = cus * per_cu;
+  const int resident = P.wave_blocks > 0 ? P.wave_blocks : 256 * RT_MIN_WAVES;     // set per device by the host API
   const int needed = (P.njobs + kWavesPerBlock - 1) / kWavesPerBlock;
   return dim3(needed < resident ? (needed > 0 ? needed : 1) : resident);
 }

@@ -36,13 +36,7 @@ __device__ __forceinline__ f3 cof(f3 m1, f3 m2) {
 }
 __device__ __forceinline__ float detc(f3 m0, f3 c) { return m0.x * c.x - m0.y * c.y + m0.z * c.z; }
 
-// native_recip of the strict oracle: the correctly rounded 1/x.
-//   RT_RCP_MODE 0: IEEE division (hipcc's correctly rounded expansion, ~11 VALU instructions)
-//   RT_RCP_MODE 1/2: v_rcp_f32 (1 ulp) refined by 1/2 Newton steps in FMA arithmetic — correctly rounded
-//   for every normal x except the inputs listed in DESIGN.md, which rt_selftest_rcp enumerates on the GPU.
-#ifndef RT_RCP_MODE
-#define RT_RCP_MODE 0
-#endif
+// v_rcp_f32 (1 ulp) refined by Newton steps in FMA arithmetic; rcp_exact below is the form the kernels use
 __device__ __forceinline__ float rcp_newton(float x, int steps) {
   float r = __builtin_amdgcn_rcpf(x);
   for (int k = 0; k < steps; ++k) {
@@ -51,20 +45,13 @@ __device__ __forceinline__ float rcp_newton(float x, int steps) {
   }
   return r;
 }
-__device__ __forceinline__ float rcp_strict(float x) {
-#if RT_RCP_MODE == 0
-  return 1.0f / x;
-#else
-  return rcp_newton(x, RT_RCP_MODE);
-#endif
-}
 
 // The correctly rounded 1/x at a third of the cost of IEEE division (13 vs 39 issue cycles, profiles/
 // r01_valu_issue_cost_8waves.txt): v_rcp_f32 + one Newton step in FMA arithmetic equals 1.0f/x bit for bit for
 // EVERY x with 2^-126 <= |x| < 2^126 (rt_selftest_rcp sweeps all 2^32 patterns on the GPU; the only
 // mismatches are denormal x and |x| >= 2^126).  For zero, denormal, infinite or NaN x the refinement
 // returns NaN, which is the cue to fall back to the division; |x| >= 2^126 cannot occur for scenes that
-// pass rt_init's coordinate bound (|coordinate| <= 2^20).
+// pass rt_init's coordinate bound (|coordinate| <= 2^16, rt_device.h kMaxCoordinate).
 __device__ __forceinline__ float rcp_exact(float x) {
   float r = rcp_newton(x, 1);
   if (r != r) r = 1.0f / x;

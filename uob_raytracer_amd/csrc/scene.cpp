@@ -117,10 +117,20 @@ int rt_scene_cornell_box(rt_triangle* out, int32_t cap) {
   return n;
 }
 
-// Loader.cpp:11-59.  Accepts exactly what the reference's parser accepts: `v x y z` and `f a b c`
-// (1-based, triangles, no slash syntax); everything else is ignored.
+// Loader.cpp:11-59: `v x y z` and `f a b c` lines (1-based indices); every other line is ignored.  Beyond the
+// reference's parser, `f` also takes "i/t/n" / "i//n" tokens, negative (relative) indices and polygons (below).
+// The constants the reference hard-codes — colour blue (0,0.2,0.4,0.5) :20, scale 1.5 :42, translation
+// (-0.4,1.15,-0.7) :48-52 — are the defaults of the _ex form.
 int rt_scene_load_obj(const char* path, rt_triangle* out, int32_t cap) {
+  return rt_scene_load_obj_ex(path, nullptr, 1.5f, nullptr, out, cap);
+}
+
+int rt_scene_load_obj_ex(const char* path, const float color[4], float scale, const float translate[3],
+                         rt_triangle* out, int32_t cap) {
   if (!path || (!out && cap > 0)) { uobrt::set_error("rt_scene_load_obj: bad arguments"); return RT_E_INVALID; }
+  const float kObjMove[3] = {-0.4f, 1.15f, -0.7f};                 // Loader.cpp:48
+  const float* const col = color ? color : kObjBlue;
+  const float* const mv = translate ? translate : kObjMove;
   FILE* f = fopen(path, "r");
   if (!f) { uobrt::set_error("rt_scene_load_obj: cannot open %s", path); return RT_E_IO; }
   std::vector<P3> verts;
@@ -135,7 +145,7 @@ int rt_scene_load_obj(const char* path, rt_triangle* out, int32_t cap) {
     if (!strcmp(tag, "v")) {
       float x, y, z;
       if (sscanf(line + used, "%f %f %f", &x, &y, &z) != 3) { rc = RT_E_IO; break; }
-      verts.push_back(P3{1.5f * x, 1.5f * y, 1.5f * z});        // Loader.cpp:42
+      verts.push_back(P3{scale * x, scale * y, scale * z});     // Loader.cpp:42 (1.5f * v)
     } else if (!strcmp(tag, "f")) {
       // Loader.cpp:44-45 reads three plain 1-based indices.  Hardening beyond the reference (which reads
       // garbage there): "i/t/n" and "i//n" tokens (the vertex index is taken), negative = relative indices,
@@ -166,13 +176,13 @@ int rt_scene_load_obj(const char* path, rt_triangle* out, int32_t cap) {
         const int a = idx[0], b = idx[j], c = idx[j + 1];
         if (n < cap) {
           rt_triangle t;
-          set_tri(&t, verts[a - 1], verts[b - 1], verts[c - 1], kObjBlue);
+          set_tri(&t, verts[a - 1], verts[b - 1], verts[c - 1], col);
           rt_triangle_compute_normal(&t);                          // normal of the UN-negated triangle, :46
           float* vs[3] = {t.v0, t.v1, t.v2};
           for (float* v : vs) {                                    // (-1)*v + (-0.4, 1.15, -0.7, 1), :48-52
-            v[0] = (-1.f) * v[0] + -0.4f;
-            v[1] = (-1.f) * v[1] + 1.15f;
-            v[2] = (-1.f) * v[2] + -0.7f;
+            v[0] = (-1.f) * v[0] + mv[0];
+            v[1] = (-1.f) * v[1] + mv[1];
+            v[2] = (-1.f) * v[2] + mv[2];
             v[3] = (-1.f) * v[3] + 1.0f;
           }
           out[n] = t;

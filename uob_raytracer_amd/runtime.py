@@ -16,7 +16,8 @@ LIB_PATH = os.environ.get("UOB_RT_LIB", os.path.join(_HERE, "libuob_rt.so"))   #
 EXPORTS = (
     "rt_abi_version", "rt_last_error", "rt_config_default", "rt_config_owned_rows", "rt_init", "rt_render",
     "rt_render_device", "rt_count_work", "rt_count_executed", "rt_last_kernel_ms", "rt_destroy", "rt_scene_cornell_box",
-    "rt_scene_load_obj", "rt_triangle_compute_normal", "rt_scene_pack", "rt_rotation_matrix", "rt_selftest_rcp",
+    "rt_scene_load_obj", "rt_scene_load_obj_ex", "rt_triangle_compute_normal", "rt_scene_pack", "rt_rotation_matrix",
+    "rt_selftest_rcp", "rt_debug_trace_rays",
 )
 
 _lib = None
@@ -51,6 +52,8 @@ def lib():
         L.rt_destroy.restype = None
         L.rt_scene_cornell_box.argtypes = [C.POINTER(abi.RtTriangle), C.c_int32]
         L.rt_scene_load_obj.argtypes = [C.c_char_p, C.POINTER(abi.RtTriangle), C.c_int32]
+        L.rt_scene_load_obj_ex.argtypes = [C.c_char_p, fp, C.c_float, fp, C.POINTER(abi.RtTriangle), C.c_int32]
+        L.rt_debug_trace_rays.argtypes = [vp, C.c_int32, fp, fp, C.c_int64, C.POINTER(C.c_int32), fp]
         L.rt_triangle_compute_normal.argtypes = [C.POINTER(abi.RtTriangle)]
         L.rt_triangle_compute_normal.restype = None
         L.rt_scene_pack.argtypes = [C.POINTER(abi.RtTriangle), C.c_int32, fp, fp, fp]
@@ -111,11 +114,13 @@ class Scene:
         return cls(np.frombuffer(buf, np.float32, n * 20).copy())
 
     @classmethod
-    def load_obj(cls, path):
-        """load_obj (Loader.cpp:11)."""
-        n = _check(lib().rt_scene_load_obj(os.fsencode(path), None, 0))
+    def load_obj(cls, path, color=None, scale=1.5, translate=None):
+        """load_obj (Loader.cpp:11); colour / scale / translation default to the reference's constants (:20,:42,:48)."""
+        col = None if color is None else _fp(np.ascontiguousarray(color, np.float32))
+        mv = None if translate is None else _fp(np.ascontiguousarray(translate, np.float32))
+        n = _check(lib().rt_scene_load_obj_ex(os.fsencode(path), col, C.c_float(scale), mv, None, 0))
         buf = (abi.RtTriangle * max(n, 1))()
-        _check(lib().rt_scene_load_obj(os.fsencode(path), buf, n))
+        _check(lib().rt_scene_load_obj_ex(os.fsencode(path), col, C.c_float(scale), mv, buf, n))
         return cls(np.frombuffer(buf, np.float32, n * 20).copy())
 
     def __add__(self, other):
@@ -205,6 +210,24 @@ class RayTracer:
             keys = ("surface_points", "stage1_wave_iterations", "stage2_wave_iterations", "sphere_wave_evaluations",
                     "culled_pairs", "tasks_resolved_whole", "sampled_points_fully_lit", "sampled_points_fully_blocked")
         return {k: int(out[i]) for i, k in enumerate(keys)}
+
+    def trace_in_shadow(self, rays, radius_sq):
+        """Device in_shadow (kernels.cl:243) on caller rays [k,6] = start, direction -> uint8 [k]."""
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        r2 = np.ascontiguousarray(radius_sq, np.float32)
+        out = np.zeros(rays.shape[0], np.int32)
+        _check(lib().rt_debug_trace_rays(self._h, abi.RT_TRACE_IN_SHADOW, _fp(rays), _fp(r2), rays.shape[0],
+                                         out.ctypes.data_as(C.POINTER(C.c_int32)), None))
+        return out.astype(np.uint8)
+
+    def trace_closest_hit(self, rays):
+        """Device single_ray_intersections (kernels.cl:168) on caller rays -> (tri [k], out [k,10])."""
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        tri = np.zeros(rays.shape[0], np.int32)
+        out = np.zeros((rays.shape[0], 10), np.float32)
+        _check(lib().rt_debug_trace_rays(self._h, abi.RT_TRACE_CLOSEST_HIT, _fp(rays), None, rays.shape[0],
+                                         tri.ctypes.data_as(C.POINTER(C.c_int32)), _fp(out)))
+        return tri, out
 
     def last_kernel_ms(self):
         ms = C.c_float()
