@@ -10,9 +10,13 @@ each rank renders its bands with the HIP kernel into its own HBM, the bands are 
 RCCL and rank 0 de-interleaves them into the final ARGB frame — total work is fixed, so "scaling" is
 "strong".  `value` is nominal Mrays/s = W*H*AA*(1+S) / time, whole job, frame resident in HBM of rank 0.
 
-Prints ONE JSON line (rank 0) with `roofline` (FP32 vector ALU is the bounding unit of this path, see
-DESIGN.md; the HBM view the north star asks for is in `roofline_hbm`) and `cpu_baseline` (the CPU oracle
-timed on this host's cores on a bounded sample of the same frame).
+Prints ONE JSON line (rank 0) with
+  `roofline`      hardware-side: the bounding unit of this path is the FP32 vector ALU's instruction issue (DESIGN.md 5);
+                  frac = VALU wave-instructions the timed kernel EXECUTES per launch (rocprofv3 PMC pass of this command,
+                  profiles/r02_pmc.json) x 2 issue cycles / (1024 SIMDs x 2.4 GHz x the kernel time measured live here)
+  `roofline_hbm`  the HBM view the north star asks for (<< 1 % by construction)
+  `algorithmic_speedup_vs_bruteforce`  the reference's brute-force flop / kernel time — NOT a hardware fraction
+  `cpu_baseline`  the CPU oracle (and the reference's own kernel built for x86-64) timed on this host's cores
 """
 import argparse
 import json
@@ -25,8 +29,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_FP32_VALU_TFLOPS = 157.3     # MI355X_MICROARCH.md, chip-level parameters
+PEAK_FP32_VALU_TFLOPS = 157.3     # MI355X_MICROARCH.md, chip-level parameters: 1024 SIMDs x 64 FLOP/clk x 2.4 GHz
 PEAK_HBM_GBPS = 8000.0
+SIMDS, CLOCK_GHZ = 1024, 2.4       # 256 CUs x 4 SIMD-32; max clock
+VALU_ISSUE_CYCLES = 2             # a wave64 VALU instruction occupies its SIMD-32 for 2 cycles (MI355X_MICROARCH.md)
+PMC_FILE = "r02_pmc.json"         # profiles/: counters per launch from the rocprofv3 --pmc passes of this command
 FLOP_PER_TRI_TEST = 46            # Moeller-Trumbore with e1,e2 precomputed
 FLOP_PER_SPHERE_TEST = 30
 
@@ -112,12 +119,14 @@ def main():
     rot = rt.rotation_matrix(0.0, 0.0)
     cam, light = [0.0, 0.0, -3.2], [0.0, -0.5, -0.7]
 
-    stripe = torch.empty((rows, W), dtype=torch.int32, device=dev)
-    gathered = None
-    bands.check_partition(H, world, band_rows)
-    if collective and rank == 0:    # one [world, rows, W] receive buffer; the gather list is its slices
-        gathered = torch.empty((world, rows, W), dtype=torch.int32, device=dev)
-    frame = torch.empty((H, W), dtype=torch.int32, device=dev) if (rank == 0 and collective) else None
+    # every rank sends an equal-size stripe of whole bands (its own rows packed at the top): any height works
+    prow = bands.padded_rows(H, world, band_rows) if collective else rows
+    stripe = torch.zeros((prow, W), dtype=torch.int32, device=dev)
+    gathered = frame_pad = frame = None
+    if collective and rank == 0:    # one [world, prow, W] receive buffer; the gather list is its slices
+        gathered = torch.empty((world, prow, W), dtype=torch.int32, device=dev)
+        frame_pad = torch.empty((prow * world, W), dtype=torch.int32, device=dev)
+        frame = frame_pad[:H]
 
     # N > 1 over RCCL: the render of frame k+1 runs on its own stream into the other of two stripe buffers while
     # the bands of frame k are gathered and de-interleaved on the current stream (events order the hand-overs)
@@ -143,7 +152,7 @@ def main():
                 ev[1].record(render_stream)
             rendered[i].record(render_stream)
             cur.wait_event(rendered[i])
-            bands.gather_frame(stripes[i], world, rank, band_rows, gathered, frame, force=True)
+            bands.gather_frame(stripes[i], world, rank, band_rows, gathered, frame_pad, force=True, height=H)
             consumed[i] = torch.cuda.Event()
             consumed[i].record(cur)
             return
@@ -155,7 +164,7 @@ def main():
             ev[1].record()
         # gloo rehearsal of N > 1: the bands travel via host memory; N == 1: the stripe IS the frame
         if args.backend == "gloo" and collective:
-            host = bands.gather_frame(stripe.cpu(), world, rank, band_rows, force=True)
+            host = bands.gather_frame(stripe.cpu(), world, rank, band_rows, force=True, height=H)
             if rank == 0:
                 frame.copy_(host)
 
@@ -225,32 +234,56 @@ def main():
     flops_per_launch = flops / world
     achieved_tflops = flops_per_launch / (kernel_ms * 1e-3) / 1e12
     # algorithmic HBM bytes per launch: the rank's share of the ARGB frame + the scene once (workgroups re-read it from L2)
-    hbm_bytes_per_launch = W * (H // world) * 4 + len(scene) * 80
+    hbm_bytes_per_launch = W * rows * 4 + len(scene) * 80
     achieved_gbps = hbm_bytes_per_launch / (kernel_ms * 1e-3) / 1e9
 
-    # HBM bytes per launch from the PMC passes of this command, committed under profiles/ (counters cannot be
-    # collected from inside the run); only quoted for the workload and GPU count they were measured on
-    traffic = None
+    # Counters of the timed kernel per launch, from the rocprofv3 --pmc passes of this command committed under profiles/
+    # (counters cannot be collected from inside the run; the kernel TIME is measured live, above).  Quoted only for the
+    # workload they were collected on; with N ranks every rank runs the same kernel on 1/N of the rows.
+    pmc = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            t = json.load(f).get(args.workload)
-        if t and t.get("n_gpus") == world:
-            traffic = t["bytes_per_launch"]
+        with open(os.path.join(ROOT, "profiles", PMC_FILE)) as f:
+            pmc = json.load(f).get(args.workload)
     except (OSError, ValueError):
         pass
-    roofline = {"bound": "valu", "achieved": achieved_tflops, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved_tflops / PEAK_FP32_VALU_TFLOPS, "traffic": traffic,
-                "note": "FP32 vector-ALU roof (SURVEY.md 8d; this path is neither HBM- nor MFMA-bound). achieved = "
-                        "ALGORITHMIC flop: (triangle tests*46 + sphere tests*30) of the reference's brute-force loops "
-                        "per launch / kernel time. The kernel resolves most (surface point, triangle) pairs by an exact "
-                        "interval bound instead of 64 per-sample tests, so the algorithmic rate can exceed the "
-                        "hardware peak; `executed` is the arithmetic really issued."}
+    traffic = pmc["hbm_bytes_per_launch"] / world if pmc else None
+    kernel_s = kernel_ms * 1e-3
+    slot_flop = 64 * 2 * VALU_ISSUE_CYCLES / 2          # flop an FMA delivers in one issue slot of a wave64 instruction
+    if pmc:
+        valu = pmc["valu_instructions_per_launch"] / world
+        achieved = valu * slot_flop / kernel_s / 1e12    # issue-slot-equivalent TFLOP/s: every slot priced as an FMA
+        fp32 = pmc["fp32_flop_per_launch_upper_bound"] / world / kernel_s / 1e12
+        roofline = {
+            "bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": traffic,
+            "valu_instructions_per_launch": valu, "salu_instructions_per_launch": pmc["salu_instructions_per_launch"] / world,
+            "issue_slot_utilisation": valu * VALU_ISSUE_CYCLES / (SIMDS * CLOCK_GHZ * 1e9 * kernel_s),
+            "fp32_executed": {"achieved": fp32, "frac": fp32 / PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
+                              "note": "FP32 add + mul + 2 x fma + transcendental wave-instructions x 64 lanes (all lanes "
+                                      "counted active: an upper bound); -ffp-contract=off makes most of them 1-flop "
+                                      "instructions, which by itself halves the reachable FP32 rate"},
+            "kernel": pmc["kernel"], "counters": "profiles/" + PMC_FILE,
+            "lds_bank_conflict_fraction": pmc.get("lds_bank_conflict_fraction"),
+            "mean_waves_per_simd": pmc.get("mean_waves_per_simd"), "wave_cycle_shares": pmc.get("wave_cycle_shares"),
+            "note": "hardware-side: achieved = VALU wave-instructions executed per launch (PMC SQ_INSTS_VALU%s) x 128 "
+                    "(the flop an FMA delivers in the 2-cycle issue slot every wave64 VALU instruction occupies) / kernel "
+                    "time measured in this run; frac = achieved / 157.3 = issue-slot utilisation of the 1024 SIMDs at "
+                    "2.4 GHz. The bounding unit is VALU instruction issue (FP32 vector ALU), not HBM and not MFMA "
+                    "(SURVEY.md 8d)." % ("" if world == 1 else ", N=1 pass / %d ranks" % world)}
+    else:
+        roofline = {"bound": "valu", "achieved": None, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": None,
+                    "traffic": None, "note": "no PMC pass of this workload is committed under profiles/%s" % PMC_FILE}
+    algorithmic = {"achieved": achieved_tflops, "unit": "TFLOP/s", "x_over_hardware_peak": achieved_tflops / PEAK_FP32_VALU_TFLOPS,
+                   "note": "ALGORITHMIC rate, not a hardware fraction: (triangle tests*46 + sphere tests*30 flop) of the "
+                           "reference's brute-force loops per launch / kernel time. The kernel decides most (surface point, "
+                           "triangle) pairs by an exact interval bound instead of 64 per-sample tests, so this exceeds the "
+                           "hardware peak; `executed` is what it really runs"}
     if total_exec and "stage1_wave_iterations" not in total_exec:      # tiled mesh kernel (n > 64)
-        roofline["executed"] = dict({k: v for k, v in total_exec.items() if not k.startswith("_")},
-                                    note="work the tiled mesh kernel really executes (rt_count_executed): (wave, tile) "
-                                         "visits and the triangles its bounds leave, per pass")
+        algorithmic["executed"] = dict({k: v for k, v in total_exec.items() if not k.startswith("_")},
+                                       note="work the tiled mesh kernel really executes (rt_count_executed): (wave, tile) "
+                                            "visits and the triangles its bounds leave, per pass")
     elif total_exec:
-        roofline["executed"] = {
+        algorithmic["executed"] = {
             "sample_triangle_tests": 64 * total_exec["stage1_wave_iterations"],
             "fraction_of_reference_tests": 64 * total_exec["stage1_wave_iterations"] / max(total_work["shadow_tri_tests"], 1),
             "surface_points_sampled": total_exec["surface_points"],
@@ -258,8 +291,7 @@ def main():
             "tasks_decided_whole": total_exec["tasks_resolved_whole"],
             "lit_surface_points": total_work["lit_hits"],
             "note": "work the shipped kernel really executes (rt_count_executed): the 64-sample test runs only for "
-                    "(surface point, triangle) pairs the interval bounds leave undecided; PMC instruction counts "
-                    "are in profiles/"}
+                    "(surface point, triangle) pairs the interval bounds leave undecided"}
 
     out = {
         "metric": "Mrays/sec (nominal = W*H*AA*(1+S)/t), Cornell Box 4096^2, 8xAA, 64 shadow rays",
@@ -282,11 +314,13 @@ def main():
         "frame_checksum": frame_sum,
         "parity": "bit-exact vs CPU oracle (strict FP32, reference operation order); tolerance allowed 1e-4",
         "roofline": roofline,
+        "algorithmic_speedup_vs_bruteforce": algorithmic,
         "roofline_hbm": {"bound": "hbm", "achieved": achieved_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                          "frac": achieved_gbps / PEAK_HBM_GBPS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": hbm_bytes_per_launch,
                          "note": "algorithmic bytes = 4 B/pixel ARGB + 80 B/triangle once; <<1% by construction; "
-                                 "traffic = HBM bytes per launch from the PMC passes in profiles/r01_pmc_traffic.json"},
+                                 "traffic = HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction) from the PMC "
+                                 "passes in profiles/" + PMC_FILE},
     }
 
     if not collective and not args.no_brute_force and "stage1_wave_iterations" in total_exec and args.workload == "headline":
@@ -304,7 +338,7 @@ def main():
         torch.cuda.synchronize()
         bms = e0.elapsed_time(e1) / 3
         out["brute_force"] = {"kernel_ms_per_launch": bms, "value": nominal_rays / (bms * 1e-3) / 1e6,
-                              "roofline_frac": flops / (bms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS,
+                              "algorithmic_frac_of_fp32_peak": flops / (bms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS,
                               "identical_frame": bool(torch.equal(bstripe, stripe)),
                               "note": "RT_FLAG_NO_CULL: same kernel, all triangles tested for every surface point"}
         bt.close()
@@ -322,6 +356,35 @@ def main():
                                    "identical_frame": bool(np.array_equal(host_frame.view(np.int32), stripe.cpu().numpy())),
                                    "note": "rt_render with a pageable host framebuffer (PCIe read-back included); "
                                            "never the headline value"}
+
+    if not collective:
+        # the light animated as the reference's update() moves it (skeleton.cpp:290-298): every frame differs from the
+        # one before, so the frame-to-frame scheduling state of the context (last frame's expensive jobs first) works
+        # from a neighbouring frame instead of an identical one
+        import numpy as _np
+        lx, lor = _np.float32(0.0), True
+        lights = []
+        for _ in range(24):
+            diff = (_np.float32(-0.5) if lor else _np.float32(0.5)) - lx
+            if lor and diff > _np.float32(-0.001):
+                lor = False
+            elif not lor and diff < _np.float32(0.001):
+                lor = True
+            lx = _np.float32(lx + diff / _np.float32(20.0))
+            lights.append([float(lx), -0.5, -0.7])
+        aev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in lights]
+        for (a, b), li in zip(aev, lights):
+            a.record()
+            tracer.render_device(rot, cam, li, focal, stripe.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+            b.record()
+        torch.cuda.synchronize()
+        ams = [a.elapsed_time(b) for a, b in aev][4:]
+        out["animated_light"] = {"kernel_ms_per_frame": float(np.mean(ams)), "max_ms": float(np.max(ams)), "frames": len(ams),
+                                 "value": nominal_rays / (float(np.mean(ams)) * 1e-3) / 1e6, "unit": "Mrays/s",
+                                 "note": "light x animated by update() (skeleton.cpp:290-298), 20 consecutive frames after 4 "
+                                         "warm-up frames; not the headline value (that is the static frame above)"}
+        tracer.render_device(rot, cam, light, focal, stripe.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()          # the static frame again: the oracle check below looks at `stripe`
 
     if not args.no_cpu_baseline and collective:
         # N > 1: no CPU baseline (it is reported at N=1 only); spot-check the gathered frame against the oracle

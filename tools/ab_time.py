@@ -8,10 +8,11 @@ import os, sys, json
 import torch
 sys.path.insert(0, os.getcwd())
 from uob_raytracer_amd import abi, runtime as rt
-cfg = abi.make_config(width=4096, height=4096, aa_x=4, aa_y=2, shadow_samples=64)
+bc = int(os.environ.get("AB_BANDS", "1"))       # time ONE rank's bands of a bc-rank job (strong scaling of the render)
+cfg = abi.make_config(width=4096, height=4096, aa_x=4, aa_y=2, shadow_samples=64, band_rows=32 if bc > 1 else 0, band_index=0, band_count=bc)
 tr = rt.RayTracer(cfg, rt.Scene.cornell_box())
 rot, cam, light = rt.rotation_matrix(0, 0), [0, 0, -3.2], [0, -0.5, -0.7]
-buf = torch.empty((4096, 4096), dtype=torch.int32, device="cuda")
+buf = torch.empty((tr.rows, 4096), dtype=torch.int32, device="cuda")
 for i in range(3): tr.render_device(rot, cam, light, 17600.0, buf.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
 torch.cuda.synchronize()
 ts = []

@@ -15,26 +15,31 @@ def band_rows_of(rank, world, height, band_rows):
     return [y for y in range(height) if (y // band_rows) % world == rank]
 
 
-def check_partition(height, world, band_rows):
-    if world > 1 and height % (band_rows * world) != 0:
-        raise ValueError("height %d must be a multiple of band_rows*world = %d for the equal-size gather"
-                         % (height, band_rows * world))
+def padded_rows(height, world, band_rows):
+    """Rows of the equal-size stripe every rank sends: whole bands, as many as the rank with the most has (rank 0).
+    Heights that are not a multiple of band_rows*world are fine: a rank renders only the rows it owns
+    (rt_config_owned_rows) into the top of its padded stripe, and the padding falls beyond the frame's last row."""
+    nbands = -(-height // band_rows)
+    return -(-nbands // world) * band_rows
 
 
-def gather_frame(stripe, world, rank, band_rows, recv=None, frame=None, dst=0, force=False):
+def gather_frame(stripe, world, rank, band_rows, recv=None, frame=None, dst=0, force=False, height=None):
     """Gather every rank's packed bands to `dst` and de-interleave them into image order.
 
-    stripe: [rows_owned, W] integer tensor (ARGB words) on this rank.  `recv`: optional preallocated
-    [world, rows_owned, W] receive buffer on `dst` (its slices are the gather list, so the bands land in one
-    allocation and the de-interleave is a single strided copy).  Returns the [H, W] frame on `dst` (written
-    into `frame` when given) and None elsewhere.  With world == 1 the stripe is the frame and no collective
-    runs, unless `force` (used to exercise the collective on one rank).
+    stripe: [padded_rows, W] integer tensor (ARGB words) on this rank, the rows it owns packed at the top.  `recv`:
+    optional preallocated [world, padded_rows, W] receive buffer on `dst` (its slices are the gather list, so the bands
+    land in one allocation and the de-interleave is a single strided copy).  `frame`: optional preallocated
+    [padded_rows * world, W] buffer.  Returns the [height, W] frame on `dst` (a view of `frame`) and None elsewhere.
+    With world == 1 the stripe is the frame and no collective runs, unless `force` (used to exercise the collective on
+    one rank).
     """
     import torch
     import torch.distributed as dist
     if world == 1 and not force:
-        return stripe
+        return stripe if height is None else stripe[:height]
     rows, width = stripe.shape
+    if rows % band_rows:
+        raise ValueError("the stripe must hold whole bands: %d rows, bands of %d (see padded_rows)" % (rows, band_rows))
     if rank == dst and recv is None:
         recv = torch.empty((world, rows, width), dtype=stripe.dtype, device=stripe.device)
     dist.gather(stripe, [recv[r] for r in range(world)] if rank == dst else None, dst=dst)
@@ -44,4 +49,4 @@ def gather_frame(stripe, world, rank, band_rows, recv=None, frame=None, dst=0, f
         frame = torch.empty((rows * world, width), dtype=stripe.dtype, device=stripe.device)
     # [rank, band, row, x] -> [band, rank, row, x] == image order
     frame.view(-1, world, band_rows, width).copy_(recv.view(world, -1, band_rows, width).permute(1, 0, 2, 3))
-    return frame
+    return frame if height is None else frame[:height]

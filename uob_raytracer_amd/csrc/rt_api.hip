@@ -15,6 +15,7 @@
 // grid.  (The one-process-per-GPU flow of bench.py gathers with RCCL through torch.distributed instead.)
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -22,6 +23,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "rt_device.h"
@@ -95,6 +97,10 @@ struct rt_ctx {
   int heavy_cap = 0, heavy_phase = 0;
   uint32_t heavy_gen = 0;
   float4* d_records = nullptr;     // staged records in HBM for meshes beyond one LDS stage
+  // mesh kernel (n > 64): the scene once more, reordered so that every 64-triangle tile is spatially compact (large
+  // triangles first, then Morton order of the centroids), the original index of each triangle, and the tiles' boxes
+  float4 *d_verts_m = nullptr, *d_normals_m = nullptr, *d_colors_m = nullptr, *d_tile_box = nullptr;
+  int* d_orig = nullptr;
   // mesh kernel: per-frame candidate-tile masks (rt_kernel_mesh.hip) and the scene's bounding box for its world grid
   unsigned long long *d_screen_masks = nullptr, *d_world_masks = nullptr;
   unsigned int* d_world_occ = nullptr;
@@ -161,6 +167,75 @@ struct DeviceGuard {
   DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
   ~DeviceGuard() { if (prev >= 0) hipSetDevice(prev); }
 };
+
+// 10 bits -> every third bit
+static uint32_t spread3(uint32_t v) {
+  v &= 1023u;
+  v = (v | (v << 16)) & 0x030000FFu;
+  v = (v | (v << 8)) & 0x0300F00Fu;
+  v = (v | (v << 4)) & 0x030C30C3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+
+// The mesh kernel's copy of the scene (rt_kernel_mesh.hip): the triangle ORDER is a free choice there — shadow tests are
+// any-hit, and the closest-hit search resolves equal t by the ORIGINAL index (the reference's loop order, kernels.cl:120)
+// — so the triangles are sorted into spatially compact tiles of 64: a task's rays then meet few tiles.  Triangles whose
+// extent exceeds a quarter of the scene's (walls) come first, the rest in Morton order of their centroids.
+static int upload_tiled_scene(rt_ctx* c, const float* v4, const float* n4, const float* c4, int n) {
+  float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+  for (size_t v = 0; v < (size_t)n * 3; ++v)
+    for (int k = 0; k < 3; ++k) { lo[k] = fminf(lo[k], v4[4 * v + k]); hi[k] = fmaxf(hi[k], v4[4 * v + k]); }
+  float ext = 0.0f;
+  for (int k = 0; k < 3; ++k) ext = fmaxf(ext, hi[k] - lo[k]);
+  const float inv = ext > 0.0f ? 1023.0f / ext : 0.0f;
+  std::vector<std::pair<uint32_t, int>> key((size_t)n);
+  for (int i = 0; i < n; ++i) {
+    const float* a = v4 + (size_t)12 * i;
+    float tl[3], th[3];
+    for (int k = 0; k < 3; ++k) { tl[k] = fminf(fminf(a[k], a[4 + k]), a[8 + k]); th[k] = fmaxf(fmaxf(a[k], a[4 + k]), a[8 + k]); }
+    const float te = fmaxf(fmaxf(th[0] - tl[0], th[1] - tl[1]), th[2] - tl[2]);
+    uint32_t code = 0u;
+    if (!(te > 0.25f * ext)) {
+      uint32_t q[3];
+      for (int k = 0; k < 3; ++k) {
+        const float f = (0.5f * (tl[k] + th[k]) - lo[k]) * inv;
+        q[k] = f >= 0.0f ? (f < 1023.0f ? (uint32_t)f : 1023u) : 0u;
+      }
+      code = 0x40000000u | spread3(q[0]) | (spread3(q[1]) << 1) | (spread3(q[2]) << 2);
+    }
+    key[(size_t)i] = std::make_pair(code, i);
+  }
+  std::stable_sort(key.begin(), key.end(), [](const std::pair<uint32_t, int>& x, const std::pair<uint32_t, int>& y) { return x.first < y.first; });
+  const int ntiles = mesh_tiles(n);
+  std::vector<float> pv((size_t)n * 12), pn((size_t)n * 4), pc((size_t)n * 4), box((size_t)ntiles * 8);
+  std::vector<int> orig((size_t)n);
+  for (int t = 0; t < ntiles; ++t) { for (int k = 0; k < 3; ++k) { box[(size_t)8 * t + k] = 3.0e38f; box[(size_t)8 * t + 4 + k] = -3.0e38f; } box[(size_t)8 * t + 3] = box[(size_t)8 * t + 7] = 0.0f; }
+  for (int j = 0; j < n; ++j) {
+    const int i = key[(size_t)j].second;
+    orig[(size_t)j] = i;
+    memcpy(&pv[(size_t)12 * j], v4 + (size_t)12 * i, 48);
+    memcpy(&pn[(size_t)4 * j], n4 + (size_t)4 * i, 16);
+    memcpy(&pc[(size_t)4 * j], c4 + (size_t)4 * i, 16);
+    float* b = &box[(size_t)8 * (j / 64)];
+    for (int v = 0; v < 3; ++v)
+      for (int k = 0; k < 3; ++k) { b[k] = fminf(b[k], v4[(size_t)12 * i + 4 * v + k]); b[4 + k] = fmaxf(b[4 + k], v4[(size_t)12 * i + 4 * v + k]); }
+  }
+  const size_t nb = (size_t)n * sizeof(float4);
+  if (hipMalloc(&c->d_verts_m, 3 * nb) != hipSuccess || hipMalloc(&c->d_normals_m, nb) != hipSuccess ||
+      hipMalloc(&c->d_colors_m, nb) != hipSuccess || hipMalloc(&c->d_orig, (size_t)n * sizeof(int)) != hipSuccess ||
+      hipMalloc(&c->d_tile_box, (size_t)ntiles * 2 * sizeof(float4)) != hipSuccess) {
+    set_error("hipMalloc failed: %s", hipGetErrorString(hipGetLastError())); return RT_E_NOMEM;
+  }
+  if (hipMemcpy(c->d_verts_m, pv.data(), 3 * nb, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(c->d_normals_m, pn.data(), nb, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(c->d_colors_m, pc.data(), nb, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(c->d_orig, orig.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(c->d_tile_box, box.data(), (size_t)ntiles * 2 * sizeof(float4), hipMemcpyHostToDevice) != hipSuccess) {
+    set_error("scene upload failed: %s", hipGetErrorString(hipGetLastError())); return RT_E_DEVICE;
+  }
+  return RT_OK;
+}
 
 extern "C" {
 
@@ -332,6 +407,10 @@ int rt_init(const rt_config* cfg, const float* vertices4, const float* normals4,
   }
   c->n_shadow = 0;
   for (int i = 0; i < n; ++i) c->n_shadow += (colors4[4 * i + 3] != -1.0f);
+  if (n > 64 && !(cfg->flags & RT_FLAG_GENERIC_KERNEL)) {
+    rc = upload_tiled_scene(c, vertices4, normals4, colors4, n);
+    if (rc != RT_OK) return fail(rc);
+  }
   *out_ctx = c;
   return RT_OK;
 }
@@ -352,6 +431,11 @@ static void fill_params(const rt_ctx* c, const float rot[12], const float cam[3]
   P->band_rows = g.band_rows; P->band_index = g.band_index; P->band_count = g.band_count;
   P->owned_rows = c->owned_rows;
   P->sy = (float)g.aa_x / (float)g.aa_y;
+  {
+    const int aa = g.aa_x * g.aa_y;
+    P->inv_S = (g.shadow_samples & (g.shadow_samples - 1)) == 0 ? 1.0f / (float)g.shadow_samples : 0.0f;
+    P->inv_aa = (aa & (aa - 1)) == 0 ? 1.0f / (float)aa : 0.0f;
+  }
   P->n_shadow = c->n_shadow;
   for (int i = 0; i < g.num_spheres; ++i) {
     P->sph[i].cx = g.spheres[i].center[0]; P->sph[i].cy = g.spheres[i].center[1]; P->sph[i].cz = g.spheres[i].center[2];
@@ -403,6 +487,12 @@ static void fill_params(const rt_ctx* c, const float rot[12], const float cam[3]
   }
 }
 
+// The mesh kernel works on the reordered copy of the scene (upload_tiled_scene)
+static void use_tiled_scene(const rt_ctx* c, FrameParams* P) {
+  P->verts = c->d_verts_m; P->normals = c->d_normals_m; P->colors = c->d_colors_m;
+  P->orig = c->d_orig; P->tile_box = c->d_tile_box;
+}
+
 // One frame of a single-device context into d_argb (packed rows, or global rows when out_global) on `stream`
 static int launch_frame(rt_ctx* c, const float rot[12], const float cam[3], const float light[3], float focal,
                         uint32_t* d_argb, float4* d_rgb, hipStream_t stream, bool out_global = false) {
@@ -439,6 +529,7 @@ static int launch_frame(rt_ctx* c, const float rot[12], const float cam[3], cons
     }
     launch_wave(P, !(c->cfg.flags & RT_FLAG_NO_CULL), false, stream);
   } else if (wave_paths && !(c->cfg.flags & RT_FLAG_NO_CULL) && mesh_kernel_supports(P)) {
+    use_tiled_scene(c, &P);
     launch_stage_records(P, stream);        // per frame: the records hold camera-dependent terms
     launch_mesh(P, false, false, stream);
   } else {
@@ -613,7 +704,7 @@ int rt_count_executed(rt_ctx* c, const float rot[12], const float cam[3], const 
   HIP_TRY(hipSetDevice(c->device));
   if (c->timed) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev1, 0));
   HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(rt_work), c->stream));
-  if (mesh) { launch_stage_records(P, c->stream); launch_mesh(P, true, c->tune.phase_profile, c->stream); }
+  if (mesh) { use_tiled_scene(c, &P); launch_stage_records(P, c->stream); launch_mesh(P, true, c->tune.phase_profile, c->stream); }
   else if (c->tune.phase_profile) launch_wave_prof(P, c->stream);   // diagnostic: s_memtime per phase
   else launch_wave(P, !(c->cfg.flags & RT_FLAG_NO_CULL), true, c->stream);
   HIP_TRY(hipGetLastError());
@@ -697,6 +788,7 @@ void rt_destroy(rt_ctx* c) {
   hipFree(c->d_argb); hipFree(c->d_rgb); hipFree(c->d_counters); hipFree(c->d_records); hipFree(c->d_jobctr);
   hipFree(c->d_screen_masks); hipFree(c->d_world_masks); hipFree(c->d_world_occ);
   hipFree(c->d_heavy[0]); hipFree(c->d_heavy[1]); hipFree(c->d_heavy_flags);
+  hipFree(c->d_verts_m); hipFree(c->d_normals_m); hipFree(c->d_colors_m); hipFree(c->d_orig); hipFree(c->d_tile_box);
   delete c;
 }
 

@@ -38,6 +38,8 @@ struct FrameParams {
   int32_t n;              // triangles
   int32_t band_rows, band_index, band_count, owned_rows;
   float sy;               // aa_x / aa_y: y sub-pixel pitch in x sub-pixel units (1 for square grids)
+  float inv_S, inv_aa;    // 1/S, 1/(aa_x*aa_y) when that count is a power of two (x / 2^k == x * 2^-k bit for bit,
+                          // one multiplication instead of an IEEE division), else 0
   int32_t n_shadow;       // triangles that can cast a shadow (glass removed), for the wave kernel
   DevSphere sph[RT_MAX_SPHERES];
   const float4* verts;    // float4[3n]  (HBM, read once per workgroup while staging into LDS)
@@ -65,6 +67,8 @@ struct FrameParams {
   int32_t heavy_factor4;              // a job is expensive above heavy_factor4 / 4 times the average job cost
   int32_t heavy_cap;
   float4* records;        // staged triangle records in HBM (8 x n float4), used when n exceeds one LDS stage
+  const int* orig;        // mesh kernel: original index of every (reordered) triangle; nullptr = the order is the original
+  const float4* tile_box; // mesh kernel: per 64-triangle tile, its vertices' box: lo.xyz, hi.xyz
   // mesh kernel: per-frame candidate-tile masks (rt_kernel_mesh.hip), nullptr = visit every tile
   unsigned long long* screen_masks;   // [scy][scx][nwords]: tiles a primary ray through that 64x64-pixel cell may hit
   unsigned long long* world_masks;    // [G][G][G][nwords]: tiles that may shadow a surface point inside that world cell

@@ -38,7 +38,7 @@ __device__ float direct_light(const LdsScene& S, const FrameParams& P, const Ray
     // mask*(light_color*max(dot,0)) / (4 pi r^2): 1.0f*x == x exactly; a shadowed sample adds 0*x
     total += sh ? 0.0f * term : term;
   }
-  return total / (float)P.S;
+  return div_count(total, P.S, P.inv_S);
 }
 
 }  // namespace
@@ -91,8 +91,8 @@ __global__ __launch_bounds__(256) void rt_draw_generic(const FrameParams P) {
         }
       }
     }
-    const float inv = (float)(P.aa_x * P.aa_y);
-    const f3 c = mk(total.x / inv, total.y / inv, total.z / inv);
+    const int aa = P.aa_x * P.aa_y;
+    const f3 c = mk(div_count(total.x, aa, P.inv_aa), div_count(total.y, aa, P.inv_aa), div_count(total.z, aa, P.inv_aa));
     const size_t o = (size_t)(P.out_global ? y : lr) * P.W + x;
     if (!COUNT) {
       P.out_argb[o] = pack_argb(c);

@@ -17,8 +17,8 @@
 // compact PTx x PTy sub-block of it: the bounds are taken over a task's rays / surface points, so their
 // footprint should be as small as possible in both directions.
 // A brute-force pass over 100 k triangles costs ~100 k tests per ray; here it costs one bound per
-// (64-ray task, triangle) plus the few real tests.  Mirror / glass bounce rays (divergent directions) take
-// the general per-lane loop over the HBM records.
+// (64-ray task, triangle) plus the few real tests.  Mirror / glass bounce rays run in rounds, the workgroup's four
+// tasks together, every round streaming all tiles through LDS with the same lane = triangle bound in front.
 #include "rt_wave_common.h"
 
 namespace uobrt {
@@ -115,29 +115,37 @@ __device__ __forceinline__ Mask2 tile_test_pair(const float4* tv0, const float4*
   return r;
 }
 
-// xorshift streams of the GP pixels of RNG group g of the current task into the wave's scratch (:319,:331)
-// Geometry of a wave's 8x8 pixel block: task k covers the PTx x PTy sub-block number k (row-major over the
-// (8/PTx) x (8/PTy) grid of sub-blocks); pixel p of a task is (p % PTx, p / PTx) inside it.
+// Geometry of a wave's 8x8 pixel block: its 64 pixels are numbered along a Z-order curve (x bits 0,2,4 / y bits
+// 1,3,5 of the number), task k covers the PT consecutive numbers from k*PT — for a power of two PT a compact
+// rectangle (4x2, 4x4, 8x4 ...), PTx >= PTy; for any other PT (AA grids such as 3x3: PT = 7) a compact run of the curve.
+__device__ __forceinline__ int zorder_x(int q) { return (q & 1) | ((q >> 1) & 2) | ((q >> 2) & 4); }
+__device__ __forceinline__ int zorder_y(int q) { return ((q >> 1) & 1) | ((q >> 2) & 2) | ((q >> 3) & 4); }
+__device__ __forceinline__ int zorder_of(int x, int y) {
+  return (x & 1) | ((y & 1) << 1) | ((x & 2) << 1) | ((y & 2) << 2) | ((x & 4) << 2) | ((y & 4) << 3);
+}
 struct BlockGeom {
   int x0, lr0;        // first pixel column / first packed local row of the 8x8 block
-  int ptx_log, pty_log;
-  __device__ __forceinline__ int PTx() const { return 1 << ptx_log; }
-  __device__ __forceinline__ int PTy() const { return 1 << pty_log; }
-  __device__ __forceinline__ int bx(int k, int p) const { return ((k & ((8 >> ptx_log) - 1)) << ptx_log) + (p & (PTx() - 1)); }
-  __device__ __forceinline__ int by(int k, int p) const { return ((k >> (3 - ptx_log)) << pty_log) + (p >> ptx_log); }
+  int PT;             // pixels per task
+  __device__ __forceinline__ int q(int k, int p) const { return k * PT + p; }
+  __device__ __forceinline__ int bx(int k, int p) const { return zorder_x(q(k, p)); }
+  __device__ __forceinline__ int by(int k, int p) const { return zorder_y(q(k, p)); }
 };
 
-__device__ __forceinline__ void generate_streams(const FrameParams& P, const MeshWaveLds& L, int lane, int GP, int NS,
+// xorshift streams of the GP pixels of RNG group g of the current task into the wave's scratch (:319,:331): the
+// `cnt` samples that follow the first `skip` ones (passes of 64 samples when there are more than 64)
+__device__ __forceinline__ void generate_streams(const FrameParams& P, const MeshWaveLds& L, int lane, int GP, int skip, int cnt,
                                                  const BlockGeom& B, int k, int first_p) {
   if (lane < 3 * GP) {
     const int pp = lane / 3, comp = lane % 3;
-    const int px = B.x0 + B.bx(k, first_p + pp);
-    const int py = band_global_row(B.lr0 + B.by(k, first_p + pp), P.band_rows, P.band_index, P.band_count);
+    const int qq = B.q(k, first_p + pp) < 64 ? B.q(k, first_p + pp) : 63;      // a pixel past the block is never lit
+    const int px = B.x0 + zorder_x(qq);
+    const int py = band_global_row(B.lr0 + zorder_y(qq), P.band_rows, P.band_index, P.band_count);
     const int gid = pixel_global_id(P, px, py);
     const uint32_t seed = comp == 0 ? (uint32_t)gid : (uint32_t)((float)gid * (comp == 1 ? 91.0f : 19.0f));
     uint32_t s = xorshift(seed);
     uint32_t* dst = L.rng + pp * kRngStride + comp;
-    for (int it = 0; it < NS; ++it) { s = xorshift(s); dst[it * 4] = s; }
+    for (int it = 0; it < skip; ++it) s = xorshift(s);
+    for (int it = 0; it < cnt; ++it) { s = xorshift(s); dst[it * 4] = s; }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -220,7 +228,10 @@ __global__ __launch_bounds__(256) void rt_bin_occupancy(const FrameParams P) {
   bool valid = i < P.n + P.nsph;
   const float amax = fmaxf(fmaxf(fmaxf(fabsf(lo.x), fabsf(hi.x)), fmaxf(fabsf(lo.y), fabsf(hi.y))), fmaxf(fabsf(lo.z), fabsf(hi.z)));
   const float lmax = fmaxf(fmaxf(fabsf(P.light[0]), fabsf(P.light[1])), fabsf(P.light[2]));
-  const float sl = 2e-4f * (lmax + amax) + 1e-5f * (1.0f + amax);
+  // a hit point on a sphere is X = start + x dir (kernels.cl:225): its rounding scales with the ray's origin — the camera
+  // for primary rays — not with the sphere's own coordinates; a point on a triangle is v0 + u e1 + v e2
+  const float cmax = fmaxf(fmaxf(fabsf(P.cam[0]), fabsf(P.cam[1])), fabsf(P.cam[2]));
+  const float sl = 2e-4f * (lmax + amax) + 1e-5f * (1.0f + amax + cmax);
   if (!(amax < 1e30f)) valid = false;               // non-finite vertices: no ray can hit such a triangle
   int c0[3], c1[3];
   const float lo3[3] = {lo.x, lo.y, lo.z}, hi3[3] = {hi.x, hi.y, hi.z};
@@ -377,20 +388,20 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
   __syncthreads();
   const LdsScene G = lds_scene(P.records, n);           // the whole mesh, in HBM (hit finalisation, bounce rays)
 
-  const int aa = P.aa_x * P.aa_y;                       // a power of two <= 64 (mesh_kernel_supports())
-  const int la = __builtin_ctz(aa);
-  const int PT = 64 >> la;                              // pixels per task
+  const int aa = P.aa_x * P.aa_y;                       // <= 64 (mesh_kernel_supports()); lanes past PT * aa idle
+  const int PT = 64 / aa;                               // pixels per task
+  const int ntask = (64 + PT - 1) / PT;                 // tasks per 8x8 block
+  const int pt_magic = (65536 + PT - 1) / PT;           // q / PT == (q * pt_magic) >> 16 for q < 64
   BlockGeom B;
   B.x0 = blockIdx.x * 16 + (wave & 1) * 8;
   B.lr0 = wg_row * 16 + (wave >> 1) * 8;                // waves past the frame still walk the tiles (barriers)
-  B.ptx_log = (6 - la + 1) >> 1;                        // PTx >= PTy, PTx * PTy = PT
-  B.pty_log = (6 - la) - B.ptx_log;
+  B.PT = PT;
   const int GP = PT < kRngPixels ? PT : kRngPixels;
   const int GL = GP * aa;
   const f3 light = mk(P.light[0], P.light[1], P.light[2]);
   const float hbox = P.spread / 2.f;
   const int NS = P.S;
-  const unsigned long long active = NS == 64 ? ~0ull : ((1ull << NS) - 1ull);
+  const int n_pass = (NS + 63) >> 6;                    // more than 64 shadow samples: passes of 64 sample lanes
   Work wk;
 
   // Candidate tiles are staged kBatch at a time (one barrier round each): 4 records x 64 triangles per tile,
@@ -407,7 +418,7 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
   };
   auto load_batch = [&](int t0, int t1, int t2, int t3, int cnt, bool primary) {
     const int rec = tid >> 6, i = tid & 63;
-    const int src = primary ? (rec == 0 ? 3 : rec == 1 ? 6 : 7) : rec;
+    const int src = primary ? (rec == 0 ? 3 : rec == 1 ? 6 : rec == 2 ? 7 : 1) : rec;    // primary slot 3: e1 | original index
     __syncthreads();
     for (int sl = 0; sl < cnt; ++sl) {
       const int t = sl == 0 ? t0 : sl == 1 ? t1 : sl == 2 ? t2 : t3;
@@ -418,31 +429,30 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
   };
 
   f3 outc = mk(0.f, 0.f, 0.f);
-  for (int k = 0; k < aa; ++k) {
+  for (int k = 0; k < ntask; ++k) {
     // ---- phase 1: primary rays over all tiles -------------------------------------------------------
-    const int p = lane >> la;                   // pixel of this lane within the task
-    const int a = lane & (aa - 1);
-    const int x = B.x0 + B.bx(k, p);
-    const int lr = B.lr0 + B.by(k, p);
-    const bool valid = lr < P.owned_rows && x < P.W;
+    const int p = (lane * P.aa_magic) >> 16;    // pixel of this lane within the task (lane / aa)
+    const int a = lane - p * aa;                // AA sample index dy*rx+dx, kernels.cl:395
+    const bool in_task = p < PT && B.q(k, p) < 64;
+    const int qz = in_task ? B.q(k, p) : B.q(k, 0);
+    const int x = B.x0 + zorder_x(qz);
+    const int lr = B.lr0 + zorder_y(qz);
+    const bool valid = in_task && lr < P.owned_rows && x < P.W;
     const int y = band_global_row(lr < P.owned_rows ? lr : 0, P.band_rows, P.band_index, P.band_count);
     Ray ray = primary_ray(P, x, y, a % P.aa_x, a / P.aa_x);
     f3 duc, eu;
     float dumax;
     {
-      // sub-pixel rectangle of the task: columns are contiguous; rows are the task's PTy packed rows, whose
-      // global y may jump at a band boundary, so take their min and max
-      const float Xlo = (float)((B.x0 + B.bx(k, 0)) * P.aa_x) - ((float)P.W * (float)P.aa_x) / 2.0f;
-      int ymin = 0x7fffffff, ymax = 0;
-      for (int r = 0; r < B.PTy(); ++r) {
-        const int lrr = B.lr0 + B.by(k, 0) + r;
-        const int yy = band_global_row(lrr < P.owned_rows ? lrr : (P.owned_rows > 0 ? P.owned_rows - 1 : 0), P.band_rows,
-                                       P.band_index, P.band_count);
-        ymin = yy < ymin ? yy : ymin; ymax = yy > ymax ? yy : ymax;
-      }
-      const float Ylo = ((float)(ymin * P.aa_y) - ((float)P.H * (float)P.aa_y) / 2.0f) * P.sy;
-      const float Yhi = ((float)(ymax * P.aa_y + P.aa_y - 1) - ((float)P.H * (float)P.aa_y) / 2.0f) * P.sy;
-      const float hx = 0.5f * (float)(B.PTx() * P.aa_x - 1), hy = 0.5f * (Yhi - Ylo);
+      // sub-pixel rectangle of the task: the bounding box of its pixels (the global row of a packed row may jump at
+      // a band boundary, and a run of the Z curve is no rectangle: take minima and maxima over the task's lanes)
+      const int yl = band_global_row(lr < P.owned_rows ? lr : (P.owned_rows > 0 ? P.owned_rows - 1 : 0), P.band_rows,
+                                     P.band_index, P.band_count);
+      const float xmin = wave_min((float)x), xmax = wave_max((float)x), ymin = wave_min((float)yl), ymax = wave_max((float)yl);
+      const float Xlo = xmin * (float)P.aa_x - ((float)P.W * (float)P.aa_x) / 2.0f;
+      const float Xhi = (xmax * (float)P.aa_x + (float)(P.aa_x - 1)) - ((float)P.W * (float)P.aa_x) / 2.0f;
+      const float Ylo = (ymin * (float)P.aa_y - ((float)P.H * (float)P.aa_y) / 2.0f) * P.sy;
+      const float Yhi = ((ymax * (float)P.aa_y + (float)(P.aa_y - 1)) - ((float)P.H * (float)P.aa_y) / 2.0f) * P.sy;
+      const float hx = 0.5f * (Xhi - Xlo), hy = 0.5f * (Yhi - Ylo);
       const f3 wc = mk(Xlo + hx, Ylo + hy, P.focal);
       const f3 r0 = mk(P.rot[0], P.rot[1], P.rot[2]), r1 = mk(P.rot[4], P.rot[5], P.rot[6]),
                r2 = mk(P.rot[8], P.rot[9], P.rot[10]);
@@ -451,12 +461,16 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
               1.0001f * (fabsf(r2.x) * hx + fabsf(r2.y) * hy));
       dumax = fmaxf(fmaxf(fabsf(duc.x) + eu.x, fabsf(duc.y) + eu.y), fabsf(duc.z) + eu.z);
     }
+    // can any primary ray of the task touch a sphere at all? (else the quadratic tests per ray are skipped)
+    const bool sph_task = P.nsph > 0 && (!(dumax < 1e30f) ||
+                          ballot(sphere_bundle_maybe(P, mk(P.cam[0], P.cam[1], P.cam[2]), 0.0f, duc, bsqrt(dot3(duc, duc)),
+                                                     1.0001f * bsqrt(dot3(eu, eu)), false)) != 0ull);
     MESH_STAMP(0)
     float current_t = RT_MAXFLOAT, bu = 0.f, bv = 0.f;
-    int best = -1;
+    int best = -1, best_o = 0x7fffffff;          // best: position in the reordered mesh; best_o: its original index
     const f3 ndp = -ray.dir;
     auto primary_tile = [&](int t, const float4* tb) {
-      const float4 *t_c = tb, *t_pc = tb + kTile, *t_qc = tb + 2 * kTile;
+      const float4 *t_c = tb, *t_pc = tb + kTile, *t_qc = tb + 2 * kTile, *t_or = tb + 3 * kTile;
       const int nc = (n - t * kTile) < kTile ? (n - t * kTile) : kTile;
       unsigned long long Kp = nc == 64 ? ~0ull : ((1ull << nc) - 1ull);
       {
@@ -473,8 +487,11 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
           const float tt = c4.w * detA_recip;
           const float u = detc(ndp, xyz(t_pc[i])) * detA_recip;
           const float v = detc(ndp, xyz(t_qc[i])) * detA_recip;
-          if (tt < current_t && u >= 0 && v >= 0 && (u + v) <= 1 && tt >= 0) {
-            best = t * kTile + i; bu = u; bv = v; current_t = tt;
+          // the reference visits the triangles in their ORIGINAL order and replaces the hit only for a strictly smaller
+          // t (kernels.cl:120): of equal t the lowest original index stays — whatever order the tiles come in
+          const int oi = __float_as_int(t_or[i].w);
+          if (u >= 0 && v >= 0 && (u + v) <= 1 && tt >= 0 && (tt < current_t || (tt == current_t && best >= 0 && oi < best_o))) {
+            best = t * kTile + i; best_o = oi; bu = u; bv = v; current_t = tt;
           }
         }
       }
@@ -505,10 +522,94 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
         ray.N = xyz(G.nrm[best]);
         ray.col = G.col[best];
       }
-      closest_spheres<false>(P, ray, current_t, wk);
+      if (sph_task) closest_spheres<false>(P, ray, current_t, wk);
       if (ray.tri != -1) {
-        if (ray.col.w <= 0.0f) { secondary = true; lit = bounce_to_diffuse<false>(G, P, ray, wk); }
+        if (ray.col.w <= 0.0f) secondary = true;
         else lit = true;
+      }
+    }
+    // ---- phase 2: mirror / glass bounces (secondary_light, kernels.cl:342-365), round by round, the workgroup's four
+    // tasks together: every round streams ALL tiles through LDS once (bounce rays have no per-frame tile masks); per
+    // tile, lane = triangle bounds the wave's bundle of bounce rays (origin box x direction box, as rt_kernel_wave.hip
+    // does per round) and the closest-hit loop visits the survivors, resolving equal t by the original index.
+    {
+      bool bouncing = secondary;
+      for (int b = 0; b < P.bounces; ++b) {
+        const bool act = bouncing && ray.col.w <= 0.0f;               // this lane's loop condition, :345
+        if (__syncthreads_or(act ? 1 : 0) == 0) break;                // workgroup-uniform
+        if (act) ray = (ray.col.w == 0.0f) ? reflect_ray(ray) : refract_ray(ray);
+        const unsigned long long actm = ballot(act);
+        int mode = 2;                                                 // 0: nothing to test, 1: bound per tile, 2: every triangle
+        f3 s0 = mk(0.f, 0.f, 0.f), D0 = s0;
+        float es = 0.f, ed = 0.f, dl = 0.f;
+        if (actm != 0ull) {
+          const f3 o = ray.start, d = ray.dir;
+          const float mag = fmaxf(fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)), fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fabsf(d.z)));
+          const bool fin = act && mag < 1e30f;                         // false for NaN as well
+          const bool isnan_ = act && !(mag == mag);                    // a NaN ray hits nothing whatever the set
+          const unsigned long long finm = ballot(fin);
+          const bool odd = ballot(act && !fin && !isnan_) != 0ull;     // infinite coordinates: no bound
+          if (finm != 0ull && !odd) {
+            const float big = 3.0e38f;
+            const f3 olo = mk(wave_min(fin ? o.x : big), wave_min(fin ? o.y : big), wave_min(fin ? o.z : big));
+            const f3 ohi = mk(wave_max(fin ? o.x : -big), wave_max(fin ? o.y : -big), wave_max(fin ? o.z : -big));
+            const f3 dlo = mk(wave_min(fin ? d.x : big), wave_min(fin ? d.y : big), wave_min(fin ? d.z : big));
+            const f3 dhi = mk(wave_max(fin ? d.x : -big), wave_max(fin ? d.y : -big), wave_max(fin ? d.z : -big));
+            s0 = 0.5f * (olo + ohi); D0 = 0.5f * (dlo + dhi);
+            es = 0.5001f * fmaxf(fmaxf(ohi.x - olo.x, ohi.y - olo.y), ohi.z - olo.z) + 1e-6f * norm1(s0);
+            ed = 0.5001f * fmaxf(fmaxf(dhi.x - dlo.x, dhi.y - dlo.y), dhi.z - dlo.z) + 1e-6f * norm1(D0);
+            const float dmx = fmaxf(fmaxf(fmaxf(fabsf(dlo.x), fabsf(dhi.x)), fmaxf(fabsf(dlo.y), fabsf(dhi.y))), fmaxf(fabsf(dlo.z), fabsf(dhi.z)));
+            dl = 1.7321f * dmx * 1.0001f;                               // >= |d|_2 of every ray
+            mode = 1;
+          } else if (finm == 0ull && !odd) {
+            mode = 0;                                                   // only NaN rays
+          }
+        }
+        float cur = RT_MAXFLOAT, hu = 0.f, hv = 0.f;
+        int hit = -1, hit_o = 0x7fffffff;
+        const f3 ndb = -ray.dir;
+        auto bounce_tile = [&](int t, const float4* tb) {
+          const float4 *t_v0 = tb, *t_e1 = tb + kTile, *t_e2 = tb + 2 * kTile, *t_c = tb + 3 * kTile;
+          if (actm == 0ull || mode == 0) return;                      // wave-uniform; the barriers are behind us
+          const int nc = (n - t * kTile) < kTile ? (n - t * kTile) : kTile;
+          unsigned long long Kb = nc == 64 ? ~0ull : ((1ull << nc) - 1ull);
+          if (mode == 1) {
+            TriLane Tb;
+            Tb.v0 = xyz(t_v0[lane]); Tb.e1 = xyz(t_e1[lane]); Tb.e2 = xyz(t_e2[lane]); Tb.c = xyz(t_c[lane]);
+            Tb.c1 = norm1(Tb.c); Tb.e1_1 = norm1(Tb.e1); Tb.e2_1 = norm1(Tb.e2);
+            Kb &= ~ballot(task_bound(Tb, s0, D0, es, ed, 2e-6f * dl, 0.0f, dl).clear);
+          }
+          if (act)
+            for (unsigned long long m = Kb; m != 0ull; m &= m - 1ull) {
+              const int i = __builtin_ctzll(m);
+              const float4 e14 = t_e1[i];
+              const f3 v0 = xyz(t_v0[i]), e1 = xyz(e14), e2 = xyz(t_e2[i]), c = xyz(t_c[i]);
+              const f3 bb = ray.start - v0;
+              const float detA_recip = rcp_exact(detc(ndb, c));
+              const float tt = detc(bb, c) * detA_recip;
+              const float u = detc(ndb, cof(bb, e2)) * detA_recip;
+              const float v = detc(ndb, cof(e1, bb)) * detA_recip;
+              const int oi = __float_as_int(e14.w);
+              if (u >= 0 && v >= 0 && (u + v) <= 1 && tt >= 0 && (tt < cur || (tt == cur && hit >= 0 && oi < hit_o))) {
+                hit = t * kTile + i; hit_o = oi; hu = u; hv = v; cur = tt;
+              }
+            }
+        };
+        for (int t0 = 0; t0 < ntiles; t0 += kBatch) {
+          const int cnt = (ntiles - t0) < kBatch ? (ntiles - t0) : kBatch;
+          load_batch(t0, t0 + 1, t0 + 2, t0 + 3, cnt, false);
+          for (int sl = 0; sl < cnt; ++sl) bounce_tile(t0 + sl, tile + sl * kSlot);
+        }
+        if (act) {
+          if (hit >= 0) {
+            ray.tri = hit;
+            ray.P = (xyz(G.v0[hit]) + hu * xyz(G.e1[hit])) + hv * xyz(G.e2[hit]);
+            ray.N = xyz(G.nrm[hit]);
+            ray.col = G.col[hit];
+          }
+          closest_spheres<false>(P, ray, cur, wk);
+          if (ray.tri != -1 && ray.col.w > 0.0f) { lit = true; bouncing = false; }
+        }
       }
     }
     // per-lane light set-up of direct_light, kernels.cl:323-326
@@ -529,15 +630,12 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
     const bool sane = lit && (radius_sq > 1e-18f) && (radius_sq < 1e30f);
     if (!sane || !(dminlen > 0.0f)) dminlen = 0.0f;
     const float dk = dlen * 1.000004f;
-    SphereBound sb;
-    sb.maybe = false; sb.all_blocked = false;
-    if (P.nsph > 0 && sane) sb = spheres_point(P, start, dir, dlen, hh);
-    const unsigned long long sphmask = ballot(lit && P.nsph > 0 && (sb.maybe || !sane));
     // Level 1 bounds a SET of surface points, and is only as tight as the set is compact.  A task whose pixels
     // straddle a silhouette holds points on surfaces far apart, so the lit points are split into groups by
     // world cell (the last group takes whatever is left) and each group is bounded on its own.
     const bool task_ok = litmask != 0ull && ballot(lit && !sane) == 0ull;
     int ngroups = 0, grp = -1;
+    bool task_sph = P.nsph > 0 && !task_ok;
     if (task_ok) {
       const int ci = bins ? world_cell(P, start) : 0;
       const float linf_l = fmaxf(fmaxf(fabsf(light.x), fabsf(light.y)), fabsf(light.z));
@@ -555,6 +653,12 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
         const float dlen_max = wave_max(in ? dlen : 0.0f);
         const float dlen_min = wave_min(in ? dlen : 3.0e38f);
         if (in) grp = ngroups;
+        if (P.nsph > 0) {     // may any shadow ray of the group touch a shadow-casting sphere?
+          const float hh_g = 1.002f * hbox + 2e-6f * (dlen_max + hbox);
+          const float s0inf = fmaxf(fmaxf(fabsf(s0.x), fabsf(s0.y)), fabsf(s0.z)), d0inf = fmaxf(fmaxf(fabsf(D0.x), fabsf(D0.y)), fabsf(D0.z));
+          task_sph = task_sph || ballot(sphere_bundle_maybe(P, s0, 1.001f * es + 2e-6f * (s0inf + es), D0, rl(dlen, jr) * 1.000001f,
+                                                            1.7321f * (1.001f * ed + 2e-6f * d0inf + hh_g), true)) != 0ull;
+        }
         if (lane == 0) {
           L.grp[4 * ngroups] = make_float4(s0.x, s0.y, s0.z, es);
           L.grp[4 * ngroups + 1] = make_float4(D0.x, D0.y, D0.z, ed);
@@ -566,13 +670,20 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+    SphereBound sb;
+    sb.maybe = false; sb.all_blocked = false;
+    if (task_sph && sane) sb = spheres_point(P, start, dir, dlen, hh);
+    const unsigned long long sphmask = ballot(lit && P.nsph > 0 && (sb.maybe || !sane));
     // this lane's pixel's xorshift stream after the seed call (kernels.cl:319), for the point-parallel level 3
     uint32_t rs0 = 0u, rs1 = 0u, rs2 = 0u;
     if (NS <= kPointSamples) {
       const int gid = pixel_global_id(P, x, y);
       rs0 = xorshift((uint32_t)gid); rs1 = xorshift((uint32_t)((float)gid * 91.0f)); rs2 = xorshift((uint32_t)((float)gid * 19.0f));
     }
-    unsigned long long my_sh = 0ull;            // blocked samples of THIS lane's surface point, across tiles
+    unsigned long long my_sh = 0ull;            // blocked samples of THIS lane's surface point (current pass), across tiles
+    unsigned long long active = 0ull;           // sample lanes of the current pass
+    int first_s = 0, cnt_s = 0;                 // its first sample and its number of samples
+    int unshadowed = 0;
     bool blocked = sane && sb.all_blocked, task_blocked = false;
     int rng_group = -1;                         // which pixel group's streams the scratch currently holds
     // candidate tiles of the workgroup's four tasks: OR of the world-cell masks of their lit surface points
@@ -690,7 +801,7 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
       for (int g = 0; g * GL < 64 && work != 0ull; ++g) {          // level 3, lane = shadow sample
         const unsigned long long gm = (work >> (g * GL)) & (GL == 64 ? ~0ull : ((1ull << GL) - 1ull));
         if (gm == 0ull) continue;
-        if (rng_group != g) { generate_streams(P, L, lane, GP, NS, B, k, g * GP); rng_group = g; }
+        if (rng_group != g) { generate_streams(P, L, lane, GP, first_s, cnt_s, B, k, g * GP); rng_group = g; }
         for (int pp = 0; pp < GP; ++pp) {
           unsigned long long pm = (gm >> (pp * aa)) & (aa == 64 ? ~0ull : ((1ull << aa) - 1ull));
           if (pm == 0ull) continue;
@@ -711,6 +822,14 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
         }
       }
     };
+    // More than 64 shadow samples: the whole traversal once per pass of 64 sample lanes (the certificates "all samples
+    // blocked" hold for every sample, so a point blocked in one pass stays out of the later ones)
+    for (int pass = 0; pass < n_pass; ++pass) {
+    first_s = pass << 6;
+    cnt_s = NS - first_s < 64 ? NS - first_s : 64;
+    active = cnt_s == 64 ? ~0ull : ((1ull << cnt_s) - 1ull);
+    my_sh = 0ull;
+    rng_group = -1;
     {
       int bw = -1;
       unsigned long long bm = 0ull;
@@ -735,7 +854,7 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
       for (int g = 0; g * GL < 64 && sw != 0ull; ++g) {
         const unsigned long long gm = (sw >> (g * GL)) & (GL == 64 ? ~0ull : ((1ull << GL) - 1ull));
         if (gm == 0ull) continue;
-        if (rng_group != g) { generate_streams(P, L, lane, GP, NS, B, k, g * GP); rng_group = g; }
+        if (rng_group != g) { generate_streams(P, L, lane, GP, first_s, cnt_s, B, k, g * GP); rng_group = g; }
         for (int pp = 0; pp < GP; ++pp) {
           unsigned long long pm = (gm >> (pp * aa)) & (aa == 64 ? ~0ull : ((1ull << aa) - 1ull));
           if (pm == 0ull) continue;
@@ -753,7 +872,9 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
         }
       }
     }
-    const int unshadowed = (blocked || task_blocked) ? 0 : __popcll(active & ~my_sh);
+    unshadowed += __popcll(active & ~my_sh);
+    }                                             // passes
+    if (blocked || task_blocked) unshadowed = 0;
 
     // ---- phase 4: shading and the AA sum, as in rt_kernel_wave.hip ---------------------------------------
     f3 contrib = mk(0.f, 0.f, 0.f);
@@ -761,34 +882,30 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
       float total = 0.0f;
       if (unshadowed < NS) total += 0.0f * term;
       for (int i = 0; i < NS; ++i) if (i < unshadowed) total += term;
-      const float l = 0.5f + total / (float)NS;
+      const float l = 0.5f + div_count(total, NS, P.inv_S);
       if (secondary) { const float kk = 0.9f * l; contrib = mk(kk * ray.col.x, kk * ray.col.y, kk * ray.col.z); }
       else contrib = mk(ray.col.x * l, ray.col.y * l, ray.col.z * l);
     }
-    f3 acc = mk(0.f, 0.f, 0.f);
-    const int first = (lane >> la) << la;
-    for (int r = 0; r < aa; ++r)
-      acc = acc + mk(shfl(contrib.x, first + r), shfl(contrib.y, first + r), shfl(contrib.z, first + r));
+    const f3 acc = aa_sum(contrib, aa, (p < PT ? p : 0) * aa);
     {   // output lane l owns block pixel (l & 7, l >> 3): take its sum from the task and pixel that cover it
-      const int obx = lane & 7, oby = lane >> 3;
-      const int ok = ((oby >> B.pty_log) << (3 - B.ptx_log)) + (obx >> B.ptx_log);
-      const int op = ((oby & (B.PTy() - 1)) << B.ptx_log) + (obx & (B.PTx() - 1));
-      const f3 v = mk(shfl(acc.x, op << la), shfl(acc.y, op << la), shfl(acc.z, op << la));
+      const int qo = zorder_of(lane & 7, lane >> 3);
+      const int ok = (qo * pt_magic) >> 16;
+      const int op = qo - ok * PT;
+      const f3 v = mk(shfl(acc.x, op * aa), shfl(acc.y, op * aa), shfl(acc.z, op * aa));
       if (ok == k) outc = v;
     }
   }
   MESH_STAMP(7)
   if (PROF) { if (lane == 0) for (int q = 0; q < 8; ++q) atomicAdd(&P.counters[q], xw[q]); return; }
   if (COUNT) {
-    xw[7] = aa;
+    xw[7] = ntask;
     if (lane == 0) for (int q = 0; q < 8; ++q) if (xw[q] && q != 6) atomicAdd(&P.counters[q], xw[q]);
     if (lane == 0) atomicMax(&P.counters[6], xw[3]);       // heaviest wave: level-1 survivors
   }
   const int x = B.x0 + (lane & 7);
   const int lr = B.lr0 + (lane >> 3);
   if (!COUNT && !PROF && lr < P.owned_rows && x < P.W) {      // the counting pass has no framebuffer
-    const float inv = (float)aa;
-    const f3 c = mk(outc.x / inv, outc.y / inv, outc.z / inv);
+    const f3 c = mk(div_count(outc.x, aa, P.inv_aa), div_count(outc.y, aa, P.inv_aa), div_count(outc.z, aa, P.inv_aa));
     const size_t o = (size_t)(P.out_global ? band_global_row(lr, P.band_rows, P.band_index, P.band_count) : lr) * P.W + x;
     P.out_argb[o] = pack_argb(c);
     if (P.out_rgb) P.out_rgb[o] = make_float4(c.x, c.y, c.z, 1.0f);
@@ -797,8 +914,7 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
 
 bool mesh_kernel_supports(const FrameParams& P) {
   const int aa = P.aa_x * P.aa_y;
-  return P.records != nullptr && P.S >= 1 && P.S <= 64 && aa >= 1 && aa <= 64 && (64 % aa) == 0 && P.n > 64 &&
-         P.spread >= 0.0f;
+  return P.records != nullptr && P.S >= 1 && P.S <= 4096 && aa >= 1 && aa <= 64 && P.n > 64 && P.spread >= 0.0f;
 }
 
 int mesh_tiles(int n) { return (n + kTile - 1) / kTile; }

@@ -35,6 +35,16 @@
 // generic kernel and to the CPU oracle.
 #include "rt_wave_common.h"
 
+#ifndef RT_OPT_SPHJOB
+#define RT_OPT_SPHJOB 1
+#endif
+#ifndef RT_OPT_TASKSPH
+#define RT_OPT_TASKSPH 1
+#endif
+#ifndef RT_OPT_PAIR
+#define RT_OPT_PAIR 1
+#endif
+
 namespace uobrt {
 
 namespace {
@@ -306,8 +316,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
   // gone, then walks on through the others (peeking with a load before spending an atomic), and leaves after a
   // full round: every head only grows, so every wave reaches the exit.
   int head = (int)((blockIdx.x * kWavesPerBlock + wave) % kJobHeads), heads_done = 0;
-  // Longest jobs first: the jobs that cost more than 4x the average in the previous frame of this context are
-  // pulled (phase A, second set of heads) before the plain sequence (phase B, which skips them by a bitmap).
+  // Longest jobs first: the jobs that cost more than heavy_factor4/4 x the average in the previous frame of this context
+  // are pulled (phase A, second set of heads) before the plain sequence (phase B, which skips them by their flag).
+  // (Handing the expensive jobs out one TASK at a time, to different waves, was built and measured: no gain at 512 rows
+  // per rank, 2 % lost on the whole frame.)
   const bool lpt = !COUNT && !PROF && P.heavy_new != nullptr;
   unsigned int n_heavy = 0u;
   unsigned long long heavy_thr = ~0ull;
@@ -319,20 +331,42 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
     n_heavy = P.heavy_prev_state[0] < (unsigned int)P.heavy_cap ? P.heavy_prev_state[0] : (unsigned int)P.heavy_cap;
     const unsigned long long psum = ((unsigned long long)P.heavy_prev_state[3] << 32) | P.heavy_prev_state[2];
     const unsigned int pjobs = P.heavy_prev_state[4];
-    if (pjobs != 0u) heavy_thr = (unsigned long long)P.heavy_factor4 * (psum / pjobs) / 4ull;
+    if (pjobs != 0u) heavy_thr = (unsigned long long)P.heavy_factor4 * (psum / pjobs) / 4ull;    // per TASK
   }
   bool phase_a = n_heavy != 0u;
+#if RT_OPT_PAIR
+  int next_job = -1;                                    // second job of the last hand-out, still to do
+  const int pair_limit = P.njobs - 8 * (int)gridDim.x * kWavesPerBlock;   // pairs until ~8 jobs per wave are left
+  bool pair_ok = pair_limit > 0;
+#endif
   for (;;) {
   int job = 0;
+  const int jt = P.job_tasks;                 // tasks of this hand-out
   if (phase_a) {
     if (lane == 0) job = (int)atomicAdd(P.job_counter + (kJobHeads + head) * kJobHeadStride, 1u);
-    const unsigned int slot = (unsigned int)__builtin_amdgcn_readfirstlane(job) * kJobHeads + (unsigned int)head;
-    if (slot >= n_heavy) { phase_a = false; continue; }
-    job = (int)P.heavy_prev[slot];
+    const unsigned int unit = (unsigned int)__builtin_amdgcn_readfirstlane(job) * kJobHeads + (unsigned int)head;
+    if (unit >= n_heavy) { phase_a = false; continue; }
+    job = (int)P.heavy_prev[unit];
     if (job < 0 || job >= P.njobs) continue;
   } else {
+#if RT_OPT_PAIR
+    // two jobs per hand-out while the queue is long (a hand-out stalls its wave for microseconds: a returning
+    // device-scope atomic), single jobs over the last stretch, where balance matters more
+    if (next_job >= 0) {
+      job = next_job; next_job = -1;
+    } else {
+      const bool two = pair_ok;
+      if (lane == 0) job = (int)atomicAdd(P.job_counter + head * kJobHeadStride, two ? 2u : 1u);
+      job = __builtin_amdgcn_readfirstlane(job) * kJobHeads + head;
+      if (two) {
+        if (job + kJobHeads < P.njobs) next_job = job + kJobHeads;
+        if (job + kJobHeads >= pair_limit) pair_ok = false;
+      }
+    }
+#else
     if (lane == 0) job = (int)atomicAdd(P.job_counter + head * kJobHeadStride, 1u);
     job = __builtin_amdgcn_readfirstlane(job) * kJobHeads + head;
+#endif
     if (job >= P.njobs) {
       bool found = false;
       while (!found && ++heads_done < kJobHeads) {
@@ -352,7 +386,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
   const int jrow = job / P.nseg;
   const int mid = (P.owned_rows + 1) >> 1;
   const int lr = (jrow & 1) ? mid + (jrow >> 1) : mid - 1 - (jrow >> 1);
-  const int JP = P.job_tasks * PT;                 // pixels per job
+  const int JP = jt * PT;                          // pixels of this hand-out
   const int x0 = (job - jrow * P.nseg) * JP;
   const int y = band_global_row(lr, P.band_rows, P.band_index, P.band_count);
   f3 outc = mk(0.f, 0.f, 0.f);
@@ -360,6 +394,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
   // rays leave the camera through a sub-pixel rectangle, see primary_clear.  (Per task the rectangle is 8x
   // narrower and a triangle or so fewer survives, but the bound itself costs more than that triangle's tests.)
   unsigned long long Kp_job = n == 64 ? ~0ull : ((1ull << n) - 1ull);
+  bool sph_job = P.nsph > 0;
   if (CULL) {
     const int lnJ = opaque(lane);
     const float Xlo = (float)(x0 * P.aa_x) - ((float)P.W * (float)P.aa_x) / 2.0f;
@@ -376,8 +411,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
     const float4 c4 = S.c[ti];
     const bool clear = primary_clear(duc, eu, dumax, xyz(c4), c4.w, xyz(S.pc[ti]), xyz(S.qc[ti]));
     if (dumax < 1e30f) Kp_job &= ~ballot(clear);
+    // ... and whether any of them can touch a sphere at all (else the two quadratic tests per ray are skipped)
+    if (RT_OPT_SPHJOB && P.nsph > 0 && dumax < 1e30f)
+      sph_job = ballot(sphere_bundle_maybe(P, mk(P.cam[0], P.cam[1], P.cam[2]), 0.0f, duc, bsqrt(dot3(duc, duc)),
+                                           1.0001f * bsqrt(dot3(eu, eu)), false)) != 0ull;
   }
-  for (int k = 0; k < P.job_tasks; ++k) {
+  for (int k = 0; k < jt; ++k) {
     const int lnA = opaque(lane);
     // ---- phase 1: 64 primary rays, lnA = (pixel, AA sample) -----------------------------------------
     const int pA = (lnA * P.aa_magic) >> 16;   // lnA / aa
@@ -389,7 +428,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
     bool lit = false, secondary = false;
     const unsigned long long Kp = Kp_job;      // triangles a primary ray of this job may hit
     if (valid) {
-      if (CULL) closest_hit_primary_masked(S, P, ray, Kp);
+      if (CULL) closest_hit_primary_masked(S, P, ray, Kp, sph_job);
       else closest_hit_primary<false>(S, P, ray, wk);
       if (ray.tri != -1) {
         // ---- phase 2: mirror / glass bounces (kernels.cl:342-365) -----------------------------------
@@ -467,13 +506,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
       const bool sane = lit && (radius_sq > 1e-18f) && (radius_sq < 1e30f);
       if (!sane || !(dminlen > 0.0f)) dminlen = 0.0f;                  // disables the distance rule
       const float dk = dlen * 1.000004f;
-      SphereBound sb;
-      sb.maybe = false; sb.all_blocked = false;
-      if (P.nsph > 0 && sane) sb = spheres_point(P, start, dir, dlen, hh);
-      sphmask = ballot(lit && P.nsph > 0 && (sb.maybe || !sane));
-      const bool sph_blocked = sane && sb.all_blocked;
       // level 1: all lit points of the task at once, lnB = triangle
       bool task_blocked = false;
+      SphereBound sb;
+      sb.maybe = false; sb.all_blocked = false;
+      bool task_sph = P.nsph > 0;                  // may any shadow ray of the task touch a shadow-casting sphere?
       {
         const int jr = __builtin_ctzll(work);
         const f3 s0 = mk(rl(start.x, jr), rl(start.y, jr), rl(start.z, jr));
@@ -490,6 +527,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
         const bool all_sane = ballot(lit && !sane) == 0ull;
         if (all_sane && es < 1e30f && ed < 1e30f) {                    // finite, non-degenerate
           const float hh_task = 1.002f * hbox + 2e-6f * (dlen_max + hbox);
+          if (RT_OPT_TASKSPH && P.nsph > 0)       // every sample direction lies within sqrt(3) (ed + hh) of D0, every start within es of s0
+            task_sph = ballot(sphere_bundle_maybe(P, s0, es, D0, dlen0, 1.7321f * (1.001f * ed + hh_task), true)) != 0ull;
           TriLane T1;
           T1.v0 = xyz(SC.v0[(lnB < ns ? lnB : 0)]); T1.e1 = xyz(SC.e1[(lnB < ns ? lnB : 0)]); T1.e2 = xyz(SC.e2[(lnB < ns ? lnB : 0)]); T1.c = xyz(SC.c[(lnB < ns ? lnB : 0)]);
           T1.c1 = norm1(T1.c); T1.e1_1 = norm1(T1.e1); T1.e2_1 = norm1(T1.e2);
@@ -498,6 +537,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
           task_blocked = (tri_lanes & ballot(tb.all_blocked)) != 0ull;
         }
       }
+      if (task_sph && !task_blocked && sane) sb = spheres_point(P, start, dir, dlen, hh);
+      sphmask = ballot(lit && P.nsph > 0 && (sb.maybe || !sane));
+      const bool sph_blocked = sane && sb.all_blocked;
       RT_STAMP(2)                           // 2: light set-up + level 1
       if (task_blocked) {
         unshadowed = 0; work = 0ull;
@@ -609,18 +651,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
         for (int i = 0; i < NS; ++i) if (i < unshadowed) total += term;
       }
       if (lit) {
-        const float l = 0.5f + total / (float)NS;
+        const float l = 0.5f + div_count(total, NS, P.inv_S);
         if (secondary) { const float kk = 0.9f * l; contrib = mk(kk * ray.col.x, kk * ray.col.y, kk * ray.col.z); }
         else contrib = mk(ray.col.x * l, ray.col.y * l, ray.col.z * l);
       }
     }
     // sum the AA rays of each pixel in index order (final_color_total +=, :415-425); a ray without a
     // contribution adds +0, which leaves the running sum unchanged bit for bit
-    f3 acc = mk(0.f, 0.f, 0.f);
-    const int first = ((lnD * P.aa_magic) >> 16) * aa;
-    for (int r = 0; r < aa; ++r) {
-      acc = acc + mk(shfl(contrib.x, first + r), shfl(contrib.y, first + r), shfl(contrib.z, first + r));
-    }
+    const f3 acc = aa_sum(contrib, aa, ((lnD * P.aa_magic) >> 16) * aa);
     // pixel pj's sum lives in lanes [pj*aa, pj*aa+aa); hand it to output lnD (k*PT + pj)
     {
       const int rel = lnD - k * PT;
@@ -633,18 +671,22 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
   // ---- store: the job's consecutive pixels, one coalesced access per wave ------------------------------
   const int x = x0 + lane;
   if (!COUNT && !PROF && lane < JP && x < P.W) {
-    const float inv = (float)aa;
-    const f3 c = mk(outc.x / inv, outc.y / inv, outc.z / inv);
+    const f3 c = mk(div_count(outc.x, aa, P.inv_aa), div_count(outc.y, aa, P.inv_aa), div_count(outc.z, aa, P.inv_aa));
     const size_t o = (size_t)(P.out_global ? y : lr) * P.W + x;
     P.out_argb[o] = pack_argb(c);
     if (P.out_rgb) P.out_rgb[o] = make_float4(c.x, c.y, c.z, 1.0f);
   }
   if (lpt) {
     const unsigned long long cost = __builtin_amdgcn_s_memtime() - job_t0;
-    if (lane == 0) { cost_acc[0] += cost; cost_acc[1] += 1ull; }
-    if (cost > heavy_thr && lane == 0) {
-      const unsigned int at = atomicAdd(P.heavy_new_state, 1u);
-      if (at < (unsigned int)P.heavy_cap) { P.heavy_new[at] = (unsigned int)job; P.heavy_flags[job] = P.heavy_gen + 1u; }
+    if (lane == 0) { cost_acc[0] += cost; cost_acc[1] += (unsigned long long)jt; }
+    if (cost > heavy_thr * (unsigned long long)jt && lane == 0) {
+      // listed once per frame, by whichever wave finds one of its tasks expensive first
+      const unsigned int was = atomicMax(P.heavy_flags + job, P.heavy_gen + 1u);
+      if (was < P.heavy_gen + 1u) {
+        const unsigned int at = atomicAdd(P.heavy_new_state, 1u);
+        if (at < (unsigned int)P.heavy_cap) P.heavy_new[at] = (unsigned int)job;
+        else atomicExch(P.heavy_flags + job, was);         // list full: not listed after all
+      }
     }
   }
   }                                          // ---- end of the job loop ---------------------------------------

@@ -58,6 +58,13 @@ __device__ __forceinline__ float rcp_exact(float x) {
   return r;
 }
 
+// x / (float)n for a wave-uniform count n (kernels.cl:338 total / light_sources, :426 final / aa_rays).  When n is a
+// power of two the host passes inv = 1/n (exact) and the quotient is the product: both are the correctly rounded
+// value of the same real number x * 2^-k, for every x (denormal results included).  inv == 0: IEEE division.
+__device__ __forceinline__ float div_count(float x, int n, float inv) {
+  return inv != 0.0f ? x * inv : x / (float)n;
+}
+
 // xorshift32 (kernels.cl:42-47), one component
 __device__ __forceinline__ uint32_t xorshift(uint32_t s) {
   s ^= s << 13;

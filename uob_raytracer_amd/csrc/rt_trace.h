@@ -8,7 +8,7 @@
 namespace uobrt {
 
 // LDS scene: float4 SoA records, one pass of staging per workgroup (stage_triangles).
-//   v0.xyz , w = colour.w | e1.xyz | e2.xyz | c = cof(e1,e2).xyz , w = det(cam-v0, e1, e2)
+//   v0.xyz , w = colour.w | e1.xyz , w = original index (bits) | e2.xyz | c = cof(e1,e2).xyz , w = det(cam-v0, e1, e2)
 //   normal | colour (w = material) | pc = cof(cam-v0, e2) | qc = cof(e1, cam-v0)
 // The last two (and c.w) are the camera-dependent terms of the PRIMARY-ray test: every primary ray
 // starts at the camera, so b = cam - v0 is the same for all of them (kernels.cl:106 with start = cam).
@@ -40,7 +40,7 @@ __device__ __forceinline__ void stage_triangles(const FrameParams& P, float4* ld
     const f3 bc = cam - v0;
     const f3 pc = cof(bc, e2), qc = cof(e1, bc);
     lds[i] = make_float4(v0.x, v0.y, v0.z, P.colors[i].w);      // w: material flag (-1 = glass casts no shadow)
-    lds[s + i] = make_float4(e1.x, e1.y, e1.z, 0.f);
+    lds[s + i] = make_float4(e1.x, e1.y, e1.z, __int_as_float(P.orig ? P.orig[i] : (int)i));   // w: original index
     lds[2 * s + i] = make_float4(e2.x, e2.y, e2.z, 0.f);
     lds[3 * s + i] = make_float4(cf.x, cf.y, cf.z, detc(bc, cf));
     lds[4 * s + i] = P.normals[i];
@@ -150,8 +150,9 @@ __device__ void closest_hit_primary(const LdsScene& S, const FrameParams& P, Ray
 // closest_hit_primary restricted to the triangles whose bit is set in `mask` (a wave-uniform 64-bit set,
 // n <= 64), visited in increasing index order so that ties on t resolve exactly as in the full loop
 // (strict '<', kernels.cl:120).  The caller guarantees that no lane's ray can hit a triangle outside it.
+// `spheres` (wave-uniform): false when the caller has shown that no ray of the wave can touch any sphere.
 __device__ inline void closest_hit_primary_masked(const LdsScene& S, const FrameParams& P, Ray& ray,
-                                                  unsigned long long mask) {
+                                                  unsigned long long mask, bool spheres = true) {
   float current_t = RT_MAXFLOAT;
   const f3 nd = -ray.dir;
   float bu = 0.f, bv = 0.f;
@@ -174,7 +175,7 @@ __device__ inline void closest_hit_primary_masked(const LdsScene& S, const Frame
     ray.col = S.col[best];
   }
   Work wk;
-  closest_spheres<false>(P, ray, current_t, wk);
+  if (spheres) closest_spheres<false>(P, ray, current_t, wk);
 }
 
 // closest_hit restricted to the triangles in `mask`, visited in index order (ties on t resolve as in the full loop)

@@ -34,13 +34,57 @@ __device__ __forceinline__ float bsqrt(float x) { return __builtin_amdgcn_sqrtf(
 __device__ __forceinline__ float uniform(float v) {
   return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
 }
+// DPP data movement: the value of another lane of the same row of 16 (row_shr / row_shl) or the last lane of the
+// previous row(s) (row_bcast), inside the VALU — no LDS round trip.  Lanes without a source keep `old`.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp(float old, float src) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, ROW_MASK, 0xf, false));
+}
+// Six dependent VALU steps (row_shr 1,2,4,8 leave each row's result in its lane 15; row_bcast:15 / :31 carry it on
+// to lane 63) instead of six ds_bpermute round trips of ~100 cycles each: the reductions sit on the critical path
+// of every task (level 1) and the kernel is latency-sensitive at 5 waves per SIMD.  Call with all 64 lanes active.
 __device__ __forceinline__ float wave_max(float v) {
-  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-  return uniform(v);
+  v = fmaxf(v, dpp<0x111, 0xf>(v, v));
+  v = fmaxf(v, dpp<0x112, 0xf>(v, v));
+  v = fmaxf(v, dpp<0x114, 0xf>(v, v));
+  v = fmaxf(v, dpp<0x118, 0xf>(v, v));
+  v = fmaxf(v, dpp<0x142, 0xa>(v, v));
+  v = fmaxf(v, dpp<0x143, 0xc>(v, v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_min(float v) {
-  for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
-  return uniform(v);
+  v = fminf(v, dpp<0x111, 0xf>(v, v));
+  v = fminf(v, dpp<0x112, 0xf>(v, v));
+  v = fminf(v, dpp<0x114, 0xf>(v, v));
+  v = fminf(v, dpp<0x118, 0xf>(v, v));
+  v = fminf(v, dpp<0x142, 0xa>(v, v));
+  v = fminf(v, dpp<0x143, 0xc>(v, v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// Sum of the aa AA rays of a pixel in index order (final_color_total +=, kernels.cl:415-425), valid in the FIRST lane
+// of each pixel's group of aa lanes [first, first + aa).  A ray without a contribution adds +0, which leaves the
+// running sum unchanged bit for bit.  For the grids whose groups do not straddle a row of 16 lanes (aa = 1,2,4,8,16)
+// lane first + r is `row_shl:r` away: one DPP add per ray; otherwise aa dependent ds_bpermute round trips.
+template <int R>
+__device__ __forceinline__ f3 add_shl(f3 acc, f3 c) {
+  return mk(acc.x + dpp<0x100 + R, 0xf>(0.f, c.x), acc.y + dpp<0x100 + R, 0xf>(0.f, c.y), acc.z + dpp<0x100 + R, 0xf>(0.f, c.z));
+}
+__device__ __forceinline__ f3 aa_sum(f3 c, int aa, int first) {
+  f3 acc = mk(0.f, 0.f, 0.f) + c;
+  if (aa <= 16 && (aa & (aa - 1)) == 0) {
+    if (aa > 1) acc = add_shl<1>(acc, c);
+    if (aa > 2) { acc = add_shl<2>(acc, c); acc = add_shl<3>(acc, c); }
+    if (aa > 4) { acc = add_shl<4>(acc, c); acc = add_shl<5>(acc, c); acc = add_shl<6>(acc, c); acc = add_shl<7>(acc, c); }
+    if (aa > 8) {
+      acc = add_shl<8>(acc, c); acc = add_shl<9>(acc, c); acc = add_shl<10>(acc, c); acc = add_shl<11>(acc, c);
+      acc = add_shl<12>(acc, c); acc = add_shl<13>(acc, c); acc = add_shl<14>(acc, c); acc = add_shl<15>(acc, c);
+    }
+    return acc;
+  }
+  acc = mk(0.f, 0.f, 0.f);
+  for (int r = 0; r < aa; ++r) acc = acc + mk(shfl(c.x, first + r), shfl(c.y, first + r), shfl(c.z, first + r));
+  return acc;
 }
 
 // Per-lane registers of a "triangle lane" (lane i < ns holds shadow-casting triangle i)
@@ -229,22 +273,24 @@ __device__ __forceinline__ bool primary_clear(f3 duc, f3 eu, float dumax, f3 c, 
   return (!can_pos && !can_neg) || cW || cE;
 }
 
-// Can any ray of a bundle — origin `o`, directions dir + e with |e|_2 <= jm — touch a sphere?  Conservative:
-// the line misses sphere (c,R) when |L x d| > R |d|; bound both sides over the bundle and leave 0.2 % for the
-// rounding of the reference's discriminant b*b - 4*a*c (kernels.cl:285, :214).  That rounding is at most
-// ~50*2^-24 * |d|^2 (|L|^2 + R^2), while the margin is worth 8*0.002 * R^2 |d|^2: rigorous for |L|/R < 73,
+// Can any ray of a bundle — origins o +- eo per component, directions dir + e with |e|_2 <= jm — touch a sphere?
+// Conservative: the line misses sphere (c,R) when |L x d| > R |d|; bound both sides over the bundle
+//   |L x d| >= |L0 x dir| - |L0| jm - sqrt(3) eo |d|,   |d| <= |dir| + jm
+// and leave 0.2 % for the rounding of the reference's discriminant b*b - 4*a*c (kernels.cl:285, :214).  That rounding
+// is at most ~50*2^-24 * |d|^2 (|L|^2 + R^2), while the margin is worth 8*0.002 * R^2 |d|^2: rigorous for |L|/R < 73,
 // applied for |L|/R < 40; farther (or degenerate) spheres are simply always tested.  The condition is
 // homogeneous in d, so it holds for the normalised directions of primary rays as well.
-//   casters_only: skip glass spheres (they cast no shadow, :279); primary rays see every sphere.
-__device__ __forceinline__ bool sphere_bundle_maybe(const FrameParams& P, f3 o, f3 dir, float dlen, float jm, bool casters_only) {
+//   casters_only: skip glass spheres (they cast no shadow, :279); primary and bounce rays see every sphere.
+__device__ __forceinline__ bool sphere_bundle_maybe(const FrameParams& P, f3 o, float eo, f3 dir, float dlen, float jm, bool casters_only) {
   bool maybe = false;
+  const float eo2 = 1.7321f * 1.001f * eo;
   for (int i = 0; i < P.nsph; ++i) {
     const DevSphere& sp = P.sph[i];
     if (casters_only && sp.col[3] == -1.0f) continue;
     const f3 Lv = o - mk(sp.cx, sp.cy, sp.cz);
     const f3 cr = mk(Lv.y * dir.z - Lv.z * dir.y, Lv.z * dir.x - Lv.x * dir.z, Lv.x * dir.y - Lv.y * dir.x);
     const float crn = bsqrt(dot3(cr, cr)), Ln = bsqrt(dot3(Lv, Lv)), R = bsqrt(fmaxf(sp.r2, 0.0f));
-    const bool miss = (crn - Ln * jm > R * (dlen + jm) * 1.002f) && (Ln < 40.0f * R) && (sp.r2 > 0.0f);
+    const bool miss = (crn - Ln * jm - eo2 * (dlen + jm) > R * (dlen + jm) * 1.002f) && (Ln + eo2 < 40.0f * R) && (sp.r2 > 0.0f);
     maybe = maybe || !miss;
   }
   return maybe;
