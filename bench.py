@@ -75,6 +75,10 @@ def main():
     ap.add_argument("--cpu-sample-pixels", type=int, default=0, help="0 = auto (about 10-30 s of CPU work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-brute-force", action="store_true", help="skip the cull-off comparison leg (N=1 only)")
+    ap.add_argument("--timed-only", action="store_true",
+                    help="only the warm-up and the timed steps (no work counters, no comparison / host-buffer / animated / "
+                         "CPU legs): what the rocprofv3 passes of tools/pmc_passes.sh run, so that every dispatch of the "
+                         "kernel in the profile is the timed workload")
     ap.add_argument("--force-collective", action="store_true",
                     help="with one rank, still initialise the process group and run the band gather (exercises the "
                          "RCCL calls of the N>1 flow on a one-GPU box)")
@@ -183,11 +187,16 @@ def main():
 
     # exact algorithmic work of this rank's bands (un-timed instrumented passes): `work` follows the
     # reference's loops literally (rt_count_work); `executed` is what the wave kernel really runs
-    work = tracer.count_work(rot, cam, light, focal)
-    try:
-        executed = tracer.count_executed(rot, cam, light, focal)
-    except rt.RtError:
+    if args.timed_only:
+        args.no_cpu_baseline = args.no_brute_force = True
+        work = {k: 0 for k, _ in abi.RtWork._fields_}
         executed = {}
+    else:
+        work = tracer.count_work(rot, cam, light, focal)
+        try:
+            executed = tracer.count_executed(rot, cam, light, focal)
+        except rt.RtError:
+            executed = {}
 
     for _ in range(args.warmup):
         step()
@@ -343,7 +352,7 @@ def main():
                               "note": "RT_FLAG_NO_CULL: same kernel, all triangles tested for every surface point"}
         bt.close()
 
-    if not collective:
+    if not collective and not args.timed_only:
         # the drop-in call itself (rt_render = offload_rendering): kernel + blocking read-back into host memory
         host_frame = np.empty((H, W), np.uint32)
         host_frame.fill(0)                       # touch the pages once, as a live screen->buffer would be
@@ -357,7 +366,7 @@ def main():
                                    "note": "rt_render with a pageable host framebuffer (PCIe read-back included); "
                                            "never the headline value"}
 
-    if not collective:
+    if not collective and not args.timed_only:
         # the light animated as the reference's update() moves it (skeleton.cpp:290-298): every frame differs from the
         # one before, so the frame-to-frame scheduling state of the context (last frame's expensive jobs first) works
         # from a neighbouring frame instead of an identical one

@@ -16,6 +16,13 @@ pytestmark = pytest.mark.gpu
     (40, 30, dict(width=48, height=32, aa_x=2, aa_y=1, shadow_samples=2)),
     (24, 16, dict(width=80, height=60, aa_x=2, aa_y=2, shadow_samples=64, light_spread=0.3)),     # wide penumbrae
     (12, 9, dict(width=70, height=41, aa_x=4, aa_y=2, shadow_samples=10, spheres=())),            # ragged frame
+    # AA grids that do not divide 64 (tasks are runs of the block's Z curve, idle lanes) and more than 64 shadow samples
+    # (passes of 64 sample lanes): on the tiled kernel too, no fall-back to the thread-per-pixel kernel
+    (12, 9, dict(width=60, height=44, aa_x=3, aa_y=3, shadow_samples=5)),
+    (10, 8, dict(width=48, height=36, aa_x=5, aa_y=1, shadow_samples=100, light_spread=0.2)),
+    (24, 16, dict(width=40, height=30, aa_x=3, aa_y=2, shadow_samples=129, max_bounces=4)),
+    (12, 9, dict(width=36, height=28, aa_x=7, aa_y=9, shadow_samples=3, spheres=())),             # 63 samples: one pixel per task
+    (12, 9, dict(width=36, height=28, aa_x=8, aa_y=8, shadow_samples=70, band_rows=5, band_index=1, band_count=2)),
 ])
 # tiled wave kernel with per-frame candidate-tile masks / the same visiting every tile / thread-per-pixel kernel
 @pytest.mark.parametrize("flags", [0, abi.RT_FLAG_NO_TILE_BINS, abi.RT_FLAG_GENERIC_KERNEL])

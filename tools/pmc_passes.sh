@@ -8,7 +8,7 @@ set -u
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; shift
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-brute-force $*"
+BENCH="python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --timed-only $*"
 cd $GRAFT_REPO_ROOT
 run() { name=$1; shift; rocprofv3 --pmc "$@" -d $OUT/pmc_$name --output-format csv -- $BENCH > $OUT/pmc_$name.log 2>&1 || echo "pass $name failed (see pmc_$name.log)"; }
 run insts   SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES

@@ -45,8 +45,8 @@ entry = {
     "mean_waves_per_simd": 4.0 * c.get("SQ_WAVE_CYCLES", 0) / max(c.get("GRBM_GUI_ACTIVE", 0) / 8.0 * 1024.0, 1) if "GRBM_GUI_ACTIVE" in c else None,
     "wave_cycle_shares": {k: c[k] / c["SQ_WAVE_CYCLES"] for k in ("SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY") if k in c and "SQ_WAVE_CYCLES" in c},
     "kernel_trace": trace,
-    "how": "tools/pmc_passes.sh: one rocprofv3 --pmc run per counter set over `bench.py --steps 3 --warmup 2 --no-cpu-baseline "
-           "--no-brute-force`, mean per dispatch of the timed kernel; kernel_trace = rocprofv3 --kernel-trace --stats of the same command",
+    "how": "tools/pmc_passes.sh: one rocprofv3 --pmc run per counter set over `bench.py --steps 10 --warmup 3 --timed-only"
+           "`, mean per dispatch of the timed kernel; kernel_trace = rocprofv3 --kernel-trace --stats of the same command",
 }
 data = json.load(open(out)) if os.path.exists(out) else {}
 data[workload] = entry
