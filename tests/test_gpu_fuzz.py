@@ -23,3 +23,12 @@ def test_fuzz_case(seed):
 def test_fuzz_case_wide_domain(seed):
     from fuzz_paths import one_case_wide
     assert one_case_wide(seed)
+
+
+@pytest.mark.parametrize("seed", [1519])
+def test_fuzz_wide_regressions(seed):
+    """1519: a camera 50 000 units from a scene of size 32 looks at a diffuse sphere inside a mesh scene.  The reference's
+    discriminant b*b - 4*a*c is then rounded by more than its own value, its "hit points" lie tens of units off the
+    sphere — and the world cells they fall into must still carry their tile masks (rt_bin_occupancy's sphere slack)."""
+    from fuzz_paths import one_case_wide
+    assert one_case_wide(seed)

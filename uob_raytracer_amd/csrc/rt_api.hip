@@ -78,6 +78,7 @@ struct Tuning {
   bool plain_order = false;   // RT_FLAG_PLAIN_ORDER or UOB_RT_PLAIN_ORDER
   bool full_grid = false;     // UOB_RT_FULL_GRID: a rank of a multi-GPU job fills every wave slot too
   bool phase_profile = false; // UOB_RT_PHASE_PROFILE: rt_count_executed returns s_memtime shares per phase
+  int mask_debug = 0;         // UOB_RT_MASK_DEBUG: mesh kernel, switch single tile-mask stages off (fault isolation)
 };
 
 struct rt_ctx {
@@ -158,6 +159,7 @@ static Tuning read_tuning(const rt_config& cfg) {
   t.plain_order = (cfg.flags & RT_FLAG_PLAIN_ORDER) != 0 || getenv("UOB_RT_PLAIN_ORDER") != nullptr;
   t.full_grid = getenv("UOB_RT_FULL_GRID") != nullptr;
   t.phase_profile = getenv("UOB_RT_PHASE_PROFILE") != nullptr;
+  if (const char* e = getenv("UOB_RT_MASK_DEBUG")) t.mask_debug = atoi(e);
   return t;
 }
 
@@ -469,6 +471,7 @@ static void fill_params(const rt_ctx* c, const float rot[12], const float cam[3]
   if (c->d_screen_masks) {
     P->screen_masks = c->d_screen_masks; P->world_masks = c->d_world_masks; P->world_occ = c->d_world_occ;
     P->nwords = c->nwords; P->scx = c->scx; P->scy = c->scy; P->grid_g = kWorldGrid;
+    P->mask_debug = c->tune.mask_debug;
     // World grid: a cube over the scene box, grown so that every shadow-ray start point X + 1e-4 (light - X)
     // of a surface point X in the box (kernels.cl:324) stays inside, rounding included; X itself is computed
     // from the camera (X = cam + t dir, or v0 + u e1 + v e2), so its rounding scales with the camera's and the
@@ -480,7 +483,14 @@ static void fill_params(const rt_ctx* c, const float rot[12], const float cam[3]
       amax = fmaxf(amax, fmaxf(fabsf(c->box_lo[k]), fabsf(c->box_hi[k])));
       cmax = fmaxf(cmax, fabsf(cam[k]));
     }
-    const float grow = 2e-4f * dmax + 1e-4f * (amax + cmax) + 1e-3f * ext + 1e-30f;
+    float grow = 2e-4f * dmax + 1e-4f * (amax + cmax) + 1e-3f * ext + 1e-30f;
+    // hit points on spheres can lie 2e-3 (|ray origin - centre| + R) off the sphere (rt_bin_occupancy): the grid holds them
+    for (int i = 0; i < g.num_spheres; ++i) {
+      float l2 = 0.0f;
+      for (int k = 0; k < 3; ++k) l2 += (cam[k] - g.spheres[i].center[k]) * (cam[k] - g.spheres[i].center[k]);
+      const float far = fmaxf(sqrtf(l2), 1.7321f * (ext + 2.0f * grow));
+      grow = fmaxf(grow, 2.5e-3f * (far + sqrtf(fmaxf(g.spheres[i].radius_sq, 0.0f))));
+    }
     for (int k = 0; k < 3; ++k) P->grid_lo[k] = c->box_lo[k] - grow;
     P->grid_cell = (ext + 2.0f * grow) / (float)kWorldGrid;
     P->grid_inv = 1.0f / P->grid_cell;

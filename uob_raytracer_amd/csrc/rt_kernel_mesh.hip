@@ -227,11 +227,21 @@ __global__ __launch_bounds__(256) void rt_bin_occupancy(const FrameParams P) {
   }
   bool valid = i < P.n + P.nsph;
   const float amax = fmaxf(fmaxf(fmaxf(fabsf(lo.x), fabsf(hi.x)), fmaxf(fabsf(lo.y), fabsf(hi.y))), fmaxf(fabsf(lo.z), fabsf(hi.z)));
-  const float lmax = fmaxf(fmaxf(fabsf(P.light[0]), fabsf(P.light[1])), fabsf(P.light[2]));
-  // a hit point on a sphere is X = start + x dir (kernels.cl:225): its rounding scales with the ray's origin — the camera
-  // for primary rays — not with the sphere's own coordinates; a point on a triangle is v0 + u e1 + v e2
-  const float cmax = fmaxf(fmaxf(fabsf(P.cam[0]), fabsf(P.cam[1])), fabsf(P.cam[2]));
-  const float sl = 2e-4f * (lmax + amax) + 1e-5f * (1.0f + amax + cmax);
+  const float lmax = max_abs3(P.light[0], P.light[1], P.light[2]);
+  // A point on a triangle is v0 + u e1 + v e2 with u, v in [0,1]: inside the triangle's box whatever the ray was.  A hit
+  // point on a SPHERE is X = start + x dir (kernels.cl:225) with x from the quadratic's discriminant b*b - 4*a*c, which
+  // the reference rounds by up to ~16 eps |d|^2 |L|^2 (L = start - centre): x is off by up to 4 sqrt(eps) |L| / |d| =
+  // 1e-3 |L| when the ray grazes the sphere — seen from a camera 50 000 units away the "hit point" lies tens of units
+  // off the sphere, and every path must still shade it the same way.  So a sphere's cells are those within
+  // 2e-3 (|L|max + R) of its box, |L|max over the camera and every possible bounce-ray origin (the scene itself).
+  const float cmax = max_abs3(P.cam[0], P.cam[1], P.cam[2]);
+  float sl = 2e-4f * (lmax + amax) + 1e-5f * (1.0f + amax + cmax);
+  if (i >= P.n && i < P.n + P.nsph) {
+    const DevSphere& sp = P.sph[i - P.n];
+    const f3 Lc = mk(P.cam[0] - sp.cx, P.cam[1] - sp.cy, P.cam[2] - sp.cz);
+    const float far = fmaxf(bsqrt(dot3(Lc, Lc)), 1.7321f * P.grid_cell * (float)G);
+    sl += 2e-3f * (far + sqrtf(fmaxf(sp.r2, 0.0f)));
+  }
   if (!(amax < 1e30f)) valid = false;               // non-finite vertices: no ray can hit such a triangle
   int c0[3], c1[3];
   const float lo3[3] = {lo.x, lo.y, lo.z}, hi3[3] = {hi.x, hi.y, hi.z};
@@ -272,6 +282,7 @@ __global__ __launch_bounds__(256) void rt_bin_occupancy(const FrameParams P) {
 }
 
 __device__ __forceinline__ bool occupied(const FrameParams& P, int level, int ix, int iy, int iz) {
+  if (P.mask_debug & 4) return true;
   const int g = P.grid_g >> level;
   const int cell = (iz * g + iy) * g + ix;
   return ((P.world_occ[occ_offset(P.grid_g, level) + (cell >> 5)] >> (cell & 31)) & 1u) != 0u;
@@ -291,7 +302,7 @@ __global__ __launch_bounds__(64 * kMeshWaves) void rt_bin_shadow(const FramePara
   T1.c = xyz(P.records[(size_t)3 * n + g]);
   T1.c1 = norm1(T1.c); T1.e1_1 = norm1(T1.e1); T1.e2_1 = norm1(T1.e2);
   const f3 light = mk(P.light[0], P.light[1], P.light[2]);
-  const float linf = fmaxf(fmaxf(fabsf(light.x), fabsf(light.y)), fabsf(light.z));
+  const float linf = norm_inf(light);
   const float hbox = P.spread / 2.f;
   const float half = 0.5f * P.grid_cell;
   const int G = P.grid_g;
@@ -300,11 +311,11 @@ __global__ __launch_bounds__(64 * kMeshWaves) void rt_bin_shadow(const FramePara
   // (slack: the rounding of that mapping); its dir = light - X (kernels.cl:323) = (light - C) + (C - X),
   // |C - X| <= hs + 1e-4 |dir|  (start = X + 1e-4 dir, :324)
   auto cell_clear = [&](f3 C, float h) {
-    const float cinf = fmaxf(fmaxf(fabsf(C.x), fabsf(C.y)), fabsf(C.z));
+    const float cinf = norm_inf(C);
     const float hs = 1.001f * h + 1e-5f * (1.0f + cinf);
     const f3 D0 = light - C;
     const float d0len = bsqrt(dot3(D0, D0));
-    const float dinf = fmaxf(fmaxf(fabsf(D0.x), fabsf(D0.y)), fabsf(D0.z));
+    const float dinf = norm_inf(D0);
     const float ed = hs + 1.1e-4f * (d0len + 2.0f * hs) + 1e-6f * (1.0f + dinf + cinf);
     const float dlen_max = (d0len + 1.7321f * ed) * 1.00001f;
     const float dlen_min = fmaxf(d0len - 1.7321f * ed, 0.0f) * 0.99999f;
@@ -371,8 +382,8 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
   unsigned long long* smask = pmask + nwords;
   const bool bins = P.screen_masks != nullptr;
   for (int w = tid; w < nwords; w += 64 * kMeshWaves) {
-    unsigned long long m = bins ? 0ull : ~0ull;
-    if (bins) {
+    unsigned long long m = (bins && !(P.mask_debug & 1)) ? 0ull : ~0ull;
+    if (bins && !(P.mask_debug & 1)) {
       const int cx = (blockIdx.x * 16) >> kScreenCellLog;
       int last = -1;
       for (int r = 0; r < 16; ++r) {                      // the workgroup's 16 packed rows: global y may jump at a band edge
@@ -544,7 +555,7 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
         float es = 0.f, ed = 0.f, dl = 0.f;
         if (actm != 0ull) {
           const f3 o = ray.start, d = ray.dir;
-          const float mag = fmaxf(fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)), fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fabsf(d.z)));
+          const float mag = fmaxf(norm_inf(o), norm_inf(d));
           const bool fin = act && mag < 1e30f;                         // false for NaN as well
           const bool isnan_ = act && !(mag == mag);                    // a NaN ray hits nothing whatever the set
           const unsigned long long finm = ballot(fin);
@@ -638,7 +649,7 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
     bool task_sph = P.nsph > 0 && !task_ok;
     if (task_ok) {
       const int ci = bins ? world_cell(P, start) : 0;
-      const float linf_l = fmaxf(fmaxf(fabsf(light.x), fabsf(light.y)), fabsf(light.z));
+      const float linf_l = norm_inf(light);
       for (unsigned long long rem = litmask; rem != 0ull; ++ngroups) {
         const int jr = __builtin_ctzll(rem);
         const int cj = __builtin_amdgcn_readlane(ci, jr);
@@ -648,14 +659,14 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
         const f3 s0 = mk(rl(start.x, jr), rl(start.y, jr), rl(start.z, jr));
         const f3 D0 = mk(rl(dir.x, jr), rl(dir.y, jr), rl(dir.z, jr));
         const f3 ds = start - s0, dd = dir - D0;
-        const float es = wave_max(in ? fmaxf(fmaxf(fabsf(ds.x), fabsf(ds.y)), fabsf(ds.z)) : 0.0f);
-        const float ed = wave_max(in ? fmaxf(fmaxf(fabsf(dd.x), fabsf(dd.y)), fabsf(dd.z)) : 0.0f);
+        const float es = wave_max(in ? norm_inf(ds) : 0.0f);
+        const float ed = wave_max(in ? norm_inf(dd) : 0.0f);
         const float dlen_max = wave_max(in ? dlen : 0.0f);
         const float dlen_min = wave_min(in ? dlen : 3.0e38f);
         if (in) grp = ngroups;
         if (P.nsph > 0) {     // may any shadow ray of the group touch a shadow-casting sphere?
           const float hh_g = 1.002f * hbox + 2e-6f * (dlen_max + hbox);
-          const float s0inf = fmaxf(fmaxf(fabsf(s0.x), fabsf(s0.y)), fabsf(s0.z)), d0inf = fmaxf(fmaxf(fabsf(D0.x), fabsf(D0.y)), fabsf(D0.z));
+          const float s0inf = norm_inf(s0), d0inf = norm_inf(D0);
           task_sph = task_sph || ballot(sphere_bundle_maybe(P, s0, 1.001f * es + 2e-6f * (s0inf + es), D0, rl(dlen, jr) * 1.000001f,
                                                             1.7321f * (1.001f * ed + 2e-6f * d0inf + hh_g), true)) != 0ull;
         }
@@ -691,7 +702,7 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
     for (int w = tid; w < nwords; w += 64 * kMeshWaves) smask[w] = 0ull;
     __syncthreads();
     if (litmask != 0ull) {
-      if (!bins || ballot(lit && !sane) != 0ull) {
+      if (!bins || (P.mask_debug & 2) || ballot(lit && !sane) != 0ull) {
         for (int w = lane; w < nwords; w += 64) atomicOr(&smask[w], ~0ull);
       } else {
         const int ci = world_cell(P, start);

@@ -451,7 +451,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
         {
           const int lnK = opaque(lane);
           const f3 o = ray.start, d = ray.dir;
-          const float mag = fmaxf(fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)), fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fabsf(d.z)));
+          const float mag = fmaxf(norm_inf(o), norm_inf(d));
           const bool fin = act && mag < 1e30f;                         // false for NaN as well
           const bool isnan_ = act && !(mag == mag);                    // a NaN ray hits nothing whatever the set
           const unsigned long long finm = ballot(fin);
@@ -519,11 +519,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
         // dir = light - X, kernels.cl:323-324), so |start - s0| <= (1 + 1e-4) |dir - D0| + roundings of the
         // coordinates, and |dir| lies within sqrt(3) ed of the reference point's.
         const f3 dd = dir - D0;
-        const float ed = wave_max(lit ? fmaxf(fmaxf(fabsf(dd.x), fabsf(dd.y)), fabsf(dd.z)) : 0.0f);
+        const float ed = wave_max(lit ? norm_inf(dd) : 0.0f);
         const float dlen0 = rl(dlen, jr);
         const float dlen_max = (dlen0 + 1.7321f * ed) * 1.000001f;
         const float dlen_min = fmaxf(dlen0 - 1.7321f * ed, 0.0f) * 0.999999f;
-        const float es = 1.0002f * ed + 2e-6f * (fmaxf(fmaxf(fabsf(light.x), fabsf(light.y)), fabsf(light.z)) + dlen_max);
+        const float es = 1.0002f * ed + 2e-6f * (norm_inf(light) + dlen_max);
         const bool all_sane = ballot(lit && !sane) == 0ull;
         if (all_sane && es < 1e30f && ed < 1e30f) {                    // finite, non-degenerate
           const float hh_task = 1.002f * hbox + 2e-6f * (dlen_max + hbox);

@@ -28,6 +28,17 @@ __device__ __forceinline__ float norm1(f3 a) { return fabsf(a.x) + fabsf(a.y) + 
 // instruction instead of the ~12 of the correctly rounded sqrtf.  Every bound that uses it carries a relative
 // slack of at least 1e-6.
 __device__ __forceinline__ float bsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+// max / min for the BOUNDS (never for a value of the reference's arithmetic): the hardware instruction as it is.  fmaxf()
+// makes the compiler quiet possible signalling NaNs first (a `v_max_f32 x, x` in front of every operand that comes
+// from a load, a readlane or a DPP move — a third of the kernel's v_max instructions); v_max_f32 / v_max3_f32 return
+// the other operand for a NaN exactly like fmaxf.
+__device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float max_abs3(float a, float b, float c) {
+  float r; asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;
+}
+__device__ __forceinline__ float norm_inf(f3 a) { return max_abs3(a.x, a.y, a.z); }
+
 // Wave-wide reductions.  The result is the same in every lane; readfirstlane tells the compiler so
 // (otherwise everything derived from it — the candidate masks, the loops over them — is treated as
 // divergent and kept in VGPRs with exec-mask loops).
@@ -44,21 +55,21 @@ __device__ __forceinline__ float dpp(float old, float src) {
 // to lane 63) instead of six ds_bpermute round trips of ~100 cycles each: the reductions sit on the critical path
 // of every task (level 1) and the kernel is latency-sensitive at 5 waves per SIMD.  Call with all 64 lanes active.
 __device__ __forceinline__ float wave_max(float v) {
-  v = fmaxf(v, dpp<0x111, 0xf>(v, v));
-  v = fmaxf(v, dpp<0x112, 0xf>(v, v));
-  v = fmaxf(v, dpp<0x114, 0xf>(v, v));
-  v = fmaxf(v, dpp<0x118, 0xf>(v, v));
-  v = fmaxf(v, dpp<0x142, 0xa>(v, v));
-  v = fmaxf(v, dpp<0x143, 0xc>(v, v));
+  v = vmax(v, dpp<0x111, 0xf>(v, v));
+  v = vmax(v, dpp<0x112, 0xf>(v, v));
+  v = vmax(v, dpp<0x114, 0xf>(v, v));
+  v = vmax(v, dpp<0x118, 0xf>(v, v));
+  v = vmax(v, dpp<0x142, 0xa>(v, v));
+  v = vmax(v, dpp<0x143, 0xc>(v, v));
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_min(float v) {
-  v = fminf(v, dpp<0x111, 0xf>(v, v));
-  v = fminf(v, dpp<0x112, 0xf>(v, v));
-  v = fminf(v, dpp<0x114, 0xf>(v, v));
-  v = fminf(v, dpp<0x118, 0xf>(v, v));
-  v = fminf(v, dpp<0x142, 0xa>(v, v));
-  v = fminf(v, dpp<0x143, 0xc>(v, v));
+  v = vmin(v, dpp<0x111, 0xf>(v, v));
+  v = vmin(v, dpp<0x112, 0xf>(v, v));
+  v = vmin(v, dpp<0x114, 0xf>(v, v));
+  v = vmin(v, dpp<0x118, 0xf>(v, v));
+  v = vmin(v, dpp<0x142, 0xa>(v, v));
+  v = vmin(v, dpp<0x143, 0xc>(v, v));
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
@@ -94,6 +105,17 @@ struct TriLane {
 };
 
 // ---- interval bounds ----------------------------------------------------------------------------------
+// The bounds are certificates, not values of the reference's arithmetic: they may be evaluated with fused multiply-adds
+// (one rounding instead of two — every slack below was sized for the unfused evaluation, so it still covers), which
+// takes a third of their instructions away.  What must stay bit-identical to the reference's own evaluation is
+// computed by the unfused helpers of rt_math.h (detc / cof): det(A0) and the cofactors p, q of point_bound, whose
+// slack is relative to the computed values themselves.
+#pragma clang fp contract(fast)
+__device__ __forceinline__ f3 bcof(f3 m1, f3 m2) {
+  return f3{m1.y * m2.z - m1.z * m2.y, m1.x * m2.z - m1.z * m2.x, m1.x * m2.y - m1.y * m2.x};
+}
+__device__ __forceinline__ float bdetc(f3 m0, f3 c) { return m0.x * c.x - m0.y * c.y + m0.z * c.z; }
+__device__ __forceinline__ float bdot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 // Level 1 (lane = triangle): can ANY shadow sample of ANY lit surface point of the current task hit this
 // triangle (`clear` = no), and do ALL of them hit it (`all_blocked`)?
 //   s0, D0 : start / dir of a reference surface point;  es, ed : max |component| deviation of the other
@@ -103,14 +125,14 @@ struct Bound { bool clear, all_blocked; };
 __device__ __forceinline__ Bound task_bound(const TriLane& T, f3 s0, f3 D0, float es, float ed, float hh,
                                             float dlen_min, float dlen_max) {
   const f3 b0 = s0 - T.v0;
-  const float binf = fmaxf(fmaxf(fabsf(b0.x), fabsf(b0.y)), fabsf(b0.z));
+  const float binf = norm_inf(b0);
   const float eb = 1.001f * es + 1e-6f * (binf + es);              // |b - b0| per component, any point
-  const float nA0 = detc(b0, T.c);
-  const f3 p0 = cof(b0, T.e2), q0 = cof(T.e1, b0);
+  const float nA0 = bdetc(b0, T.c);
+  const f3 p0 = bcof(b0, T.e2), q0 = bcof(T.e1, b0);
   const float p1 = norm1(p0), q1 = norm1(q0);
   const float ep1 = 2.002f * eb * T.e2_1, eq1 = 2.002f * eb * T.e1_1;   // sum_k |p_k - p0_k|, |q_k - q0_k|
   const f3 md = -D0;
-  const float A0 = detc(md, T.c), N1 = detc(md, p0), N2 = detc(md, q0);
+  const float A0 = bdetc(md, T.c), N1 = bdetc(md, p0), N2 = bdetc(md, q0);
   const float edd = 1.001f * ed + hh;                               // |d - D0| per component, any point, any sample
   const float E0 = eb * T.c1 * 1.0001f;
   const float EA = edd * T.c1 * 1.0001f;
@@ -123,9 +145,9 @@ __device__ __forceinline__ Bound task_bound(const TriLane& T, f3 s0, f3 D0, floa
   const float dmin = fmaxf(dlen_min - 1.7321f * hh, 0.0f), dmax = dlen_max + 1.7321f * hh;
   // the third edge as ONE linear function of the direction (see point_bound): det(-d, b - e1, e2 - e1)
   const f3 g = T.e2 - T.e1;
-  const f3 w0 = cof(b0 - T.e1, g);
+  const f3 w0 = bcof(b0 - T.e1, g);
   const float w1 = norm1(w0), ew1 = 2.002f * eb * norm1(g);
-  const float W0 = sg * detc(md, w0);
+  const float W0 = sg * bdetc(md, w0);
   const float EW = (dlen_max * ew1 + edd * (w1 + ew1)) * 1.0001f;
   const float slackW = 4e-6f * (dlen_max + hh) * (((p1 + ep1) + (q1 + eq1) + T.c1) +
                                                   (norm1(b0) + 3.0f * eb + T.e1_1) * (T.e1_1 + T.e2_1));
@@ -159,19 +181,19 @@ __device__ __forceinline__ Bound task_bound(const TriLane& T, f3 s0, f3 D0, floa
 __device__ __forceinline__ Bound light_bundle_bound(const TriLane& T, f3 light, f3 s0, float es, f3 D0, float ed, float hh,
                                                     float dlen_min, float dlen_max, float M) {
   const f3 Lv = light - T.v0;
-  const float Linf = fmaxf(fmaxf(fabsf(Lv.x), fabsf(Lv.y)), fabsf(Lv.z));
-  const f3 pL = cof(Lv, T.e2), qL = cof(T.e1, Lv);
+  const float Linf = norm_inf(Lv);
+  const f3 pL = bcof(Lv, T.e2), qL = bcof(T.e1, Lv);
   const f3 b0 = s0 - T.v0;
-  const float binf = fmaxf(fmaxf(fabsf(b0.x), fabsf(b0.y)), fabsf(b0.z));
+  const float binf = norm_inf(b0);
   const float eb = 1.001f * es + 1e-6f * (binf + es);                // |b - b0| per component, any point
-  const float pj = norm1(cof(b0, T.e2)) + 2.002f * eb * T.e2_1;      // >= |cof(b,e2)|_1, any point
-  const float qj = norm1(cof(T.e1, b0)) + 2.002f * eb * T.e1_1;
+  const float pj = norm1(bcof(b0, T.e2)) + 2.002f * eb * T.e2_1;      // >= |bcof(b,e2)|_1, any point
+  const float qj = norm1(bcof(T.e1, b0)) + 2.002f * eb * T.e1_1;
   const f3 md = -D0;
-  const float A0 = detc(md, T.c), N1 = detc(md, pL), N2 = detc(md, qL);
-  const float nA0 = detc(Lv, T.c) + 0.9999f * A0;                    // L.c - (1 - eps) D0.c
+  const float A0 = bdetc(md, T.c), N1 = bdetc(md, pL), N2 = bdetc(md, qL);
+  const float nA0 = bdetc(Lv, T.c) + 0.9999f * A0;                    // L.c - (1 - eps) D0.c
   const float ed1 = 1.001f * ed;                                     // |dir - D0| per component, any point
   const float Bmax = Linf + dlen_max;                                // |b| per component
-  const float rnd = 8e-6f * dlen_max * (Bmax + M);                   // roundings of cof(b,e), of the dots, Delta
+  const float rnd = 8e-6f * dlen_max * (Bmax + M);                   // roundings of bcof(b,e), of the dots, Delta
   const float E0 = (ed1 + 4e-6f * (M + Bmax)) * T.c1 * 1.0001f;
   const float EA = (ed1 + hh) * T.c1 * 1.0001f;
   const float E1 = (ed1 * norm1(pL) + hh * pj + rnd * T.e2_1) * 1.0001f;
@@ -182,12 +204,12 @@ __device__ __forceinline__ Bound light_bundle_bound(const TriLane& T, f3 light, 
   const float tn = sg * nA0, un = sg * N1, vn = sg * N2;
   const float dmin = fmaxf(dlen_min - 1.7321f * hh, 0.0f), dmax = dlen_max + 1.7321f * hh;
   // the third edge as one linear function (see point_bound): det(A1)+det(A2)-det(A) = -dir.wL - j.wb,
-  // wL = cof(L - e1, e2 - e1), wb = cof(b - e1, e2 - e1)
+  // wL = bcof(L - e1, e2 - e1), wb = bcof(b - e1, e2 - e1)
   const f3 g = T.e2 - T.e1;
   const float g1 = norm1(g);
-  const f3 wL = cof(Lv - T.e1, g);
-  const float wj = norm1(cof(b0 - T.e1, g)) + 2.002f * eb * g1;      // >= |wb|_1, any point
-  const float W0 = sg * detc(md, wL);
+  const f3 wL = bcof(Lv - T.e1, g);
+  const float wj = norm1(bcof(b0 - T.e1, g)) + 2.002f * eb * g1;      // >= |wb|_1, any point
+  const float W0 = sg * bdetc(md, wL);
   const float EW = (ed1 * norm1(wL) + hh * wj + rnd * g1) * 1.0001f;
   const float slackW = 4e-6f * (dlen_max + hh) * ((pj + qj + T.c1) +
                                                   (norm1(Lv) + norm1(b0) + 3.0f * eb + T.e1_1) * (T.e1_1 + T.e2_1));
@@ -210,10 +232,10 @@ __device__ __forceinline__ Bound light_bundle_bound(const TriLane& T, f3 light, 
 __device__ __forceinline__ Bound point_bound(f3 start, f3 dir, float hh, float dlen, float dminlen, float dk,
                                              f3 v0, f3 e1, f3 e2, f3 c) {
   const f3 b = start - v0;
-  const f3 p = cof(b, e2), q = cof(e1, b);
-  const float nA0 = detc(b, c);
+  const f3 p = cof(b, e2), q = cof(e1, b);       // unfused: the reference's own p, q (their slack is relative to them)
+  const float nA0 = detc(b, c);                   // unfused: the reference's det(A0), bit for bit
   const f3 md = -dir;
-  const float D0 = detc(md, c), N1 = detc(md, p), N2 = detc(md, q);
+  const float D0 = bdetc(md, c), N1 = bdetc(md, p), N2 = bdetc(md, q);
   const float aD = fabsf(D0);
   const float c1 = norm1(c), p1 = norm1(p), q1 = norm1(q);
   const float Delta = hh * c1;
@@ -228,8 +250,8 @@ __device__ __forceinline__ Bound point_bound(f3 start, f3 dir, float hh, float d
   // a ray skimming along a face passes its top edge at u+v = 1.03 for every sample, yet the three separate
   // intervals overlap.)  slack: the reference rounds u, v and u+v (a few 2^-24 of |d| (|p|+|q|+|c|)), and w is not
   // formed the way the reference forms p, q and c (a few 2^-24 of |d| (|b|+|e1|) (|e1|+|e2|), whatever cancels).
-  const f3 w = cof(b - e1, e2 - e1);
-  const float W0 = sg * detc(md, w), hw = hh * norm1(w);
+  const f3 w = bcof(b - e1, e2 - e1);
+  const float W0 = sg * bdetc(md, w), hw = hh * norm1(w);
   // second term: w is rounded like any product of (b - e1) and (e2 - e1) however small p, q and c come out
   const float e1n = norm1(e1);
   const float slackW = 4e-6f * (dlen + hh) * ((p1 + q1 + c1) + (norm1(b) + e1n) * (e1n + norm1(e2)));
@@ -255,7 +277,7 @@ __device__ __forceinline__ Bound point_bound(f3 start, f3 dir, float hh, float d
 // and of the per-ray determinant evaluation (each a few 2^-24 relative to |du|_max * |cofactors|_1).
 __device__ __forceinline__ bool primary_clear(f3 duc, f3 eu, float dumax, f3 c, float nA0cam, f3 pc, f3 qc) {
   const f3 md = -duc;
-  const float Ac = detc(md, c), N1 = detc(md, pc), N2 = detc(md, qc);
+  const float Ac = bdetc(md, c), N1 = bdetc(md, pc), N2 = bdetc(md, qc);
   const float sl = 4e-6f * dumax;
   const float EA = eu.x * fabsf(c.x) + eu.y * fabsf(c.y) + eu.z * fabsf(c.z) + sl * norm1(c);
   const float E1 = eu.x * fabsf(pc.x) + eu.y * fabsf(pc.y) + eu.z * fabsf(pc.z) + sl * norm1(pc);
@@ -267,7 +289,7 @@ __device__ __forceinline__ bool primary_clear(f3 duc, f3 eu, float dumax, f3 c, 
   // from the staged cofactors, the rounding of that sum and of the reference's u, v, u+v goes into the slack
   const f3 w = (pc + qc) - c;
   const float cn = norm1(c) + norm1(pc) + norm1(qc);
-  const float W = copysignf(1.0f, Ac) * detc(md, w);
+  const float W = copysignf(1.0f, Ac) * bdetc(md, w);
   const float EW = eu.x * fabsf(w.x) + eu.y * fabsf(w.y) + eu.z * fabsf(w.z) + 2.0f * sl * cn;
   const bool cE = (fabsf(Ac) > EA) && (W - EW > 0.0f);           // u+v > 1 for every ray of the bundle
   return (!can_pos && !can_neg) || cW || cE;
@@ -289,7 +311,7 @@ __device__ __forceinline__ bool sphere_bundle_maybe(const FrameParams& P, f3 o, 
     if (casters_only && sp.col[3] == -1.0f) continue;
     const f3 Lv = o - mk(sp.cx, sp.cy, sp.cz);
     const f3 cr = mk(Lv.y * dir.z - Lv.z * dir.y, Lv.z * dir.x - Lv.x * dir.z, Lv.x * dir.y - Lv.y * dir.x);
-    const float crn = bsqrt(dot3(cr, cr)), Ln = bsqrt(dot3(Lv, Lv)), R = bsqrt(fmaxf(sp.r2, 0.0f));
+    const float crn = bsqrt(bdot3(cr, cr)), Ln = bsqrt(bdot3(Lv, Lv)), R = bsqrt(fmaxf(sp.r2, 0.0f));
     const bool miss = (crn - Ln * jm - eo2 * (dlen + jm) > R * (dlen + jm) * 1.002f) && (Ln + eo2 < 40.0f * R) && (sp.r2 > 0.0f);
     maybe = maybe || !miss;
   }
@@ -315,18 +337,20 @@ __device__ __forceinline__ SphereBound spheres_point(const FrameParams& P, f3 st
     const f3 Lv = start - mk(sp.cx, sp.cy, sp.cz);
     const f3 cr = mk(Lv.y * dir.z - Lv.z * dir.y, Lv.z * dir.x - Lv.x * dir.z, Lv.x * dir.y - Lv.y * dir.x);
     const f3 cl = mk(cr.y * Lv.z - cr.z * Lv.y, cr.z * Lv.x - cr.x * Lv.z, cr.x * Lv.y - cr.y * Lv.x);     // cr x L
-    const float crn = bsqrt(dot3(cr, cr)), Ln2 = dot3(Lv, Lv), Ln = bsqrt(Ln2), R = bsqrt(fmaxf(sp.r2, 0.0f));
+    const float crn = bsqrt(bdot3(cr, cr)), Ln2 = bdot3(Lv, Lv), Ln = bsqrt(Ln2), R = bsqrt(fmaxf(sp.r2, 0.0f));
     const bool near = (Ln < 40.0f * R) && (sp.r2 > 0.0f);
     const bool miss = near && (crn * crn - hh * norm1(cl) > R * (dlen + jm) * 1.002f * crn);
     r.maybe = r.maybe || !miss;
     // all samples: start outside the sphere, sphere ahead of the start and wholly nearer than the light
     // (then both roots are positive and the near one lies within |L| of the start), line through the sphere
-    const bool hit = near && (Ln2 > 1.001f * sp.r2) && (dot3(dir, Lv) + hh * norm1(Lv) < 0.0f) && (Ln < 0.999f * dlen) &&
+    const bool hit = near && (Ln2 > 1.001f * sp.r2) && (bdot3(dir, Lv) + hh * norm1(Lv) < 0.0f) && (Ln < 0.999f * dlen) &&
                      (crn + Ln * jm < 0.99f * R * (dlen - jm)) && (dlen > jm);
     r.all_blocked = r.all_blocked || hit;
   }
   return r;
 }
+
+#pragma clang fp contract(off)
 
 }  // namespace
 }  // namespace uobrt
