@@ -458,7 +458,7 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
       // a band boundary, and a run of the Z curve is no rectangle: take minima and maxima over the task's lanes)
       const int yl = band_global_row(lr < P.owned_rows ? lr : (P.owned_rows > 0 ? P.owned_rows - 1 : 0), P.band_rows,
                                      P.band_index, P.band_count);
-      const float xmin = wave_min((float)x), xmax = wave_max((float)x), ymin = wave_min((float)yl), ymax = wave_max((float)yl);
+      const float xmin = wave_min_pos((float)x), xmax = wave_max_pos((float)x), ymin = wave_min_pos((float)yl), ymax = wave_max_pos((float)yl);
       const float Xlo = xmin * (float)P.aa_x - ((float)P.W * (float)P.aa_x) / 2.0f;
       const float Xhi = (xmax * (float)P.aa_x + (float)(P.aa_x - 1)) - ((float)P.W * (float)P.aa_x) / 2.0f;
       const float Ylo = (ymin * (float)P.aa_y - ((float)P.H * (float)P.aa_y) / 2.0f) * P.sy;
@@ -659,10 +659,10 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
         const f3 s0 = mk(rl(start.x, jr), rl(start.y, jr), rl(start.z, jr));
         const f3 D0 = mk(rl(dir.x, jr), rl(dir.y, jr), rl(dir.z, jr));
         const f3 ds = start - s0, dd = dir - D0;
-        const float es = wave_max(in ? norm_inf(ds) : 0.0f);
-        const float ed = wave_max(in ? norm_inf(dd) : 0.0f);
-        const float dlen_max = wave_max(in ? dlen : 0.0f);
-        const float dlen_min = wave_min(in ? dlen : 3.0e38f);
+        const float es = wave_max_pos(in ? norm_inf(ds) : 0.0f);
+        const float ed = wave_max_pos(in ? norm_inf(dd) : 0.0f);
+        const float dlen_max = wave_max_pos(in ? dlen : 0.0f);
+        const float dlen_min = wave_min_pos(in ? dlen : 3.0e38f);
         if (in) grp = ngroups;
         if (P.nsph > 0) {     // may any shadow ray of the group touch a shadow-casting sphere?
           const float hh_g = 1.002f * hbox + 2e-6f * (dlen_max + hbox);

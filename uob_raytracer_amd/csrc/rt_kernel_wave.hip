@@ -519,7 +519,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
         // dir = light - X, kernels.cl:323-324), so |start - s0| <= (1 + 1e-4) |dir - D0| + roundings of the
         // coordinates, and |dir| lies within sqrt(3) ed of the reference point's.
         const f3 dd = dir - D0;
-        const float ed = wave_max(lit ? norm_inf(dd) : 0.0f);
+        const float ed = wave_max_pos(lit ? norm_inf(dd) : 0.0f);
         const float dlen0 = rl(dlen, jr);
         const float dlen_max = (dlen0 + 1.7321f * ed) * 1.000001f;
         const float dlen_min = fmaxf(dlen0 - 1.7321f * ed, 0.0f) * 0.999999f;

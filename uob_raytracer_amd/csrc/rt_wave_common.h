@@ -28,16 +28,12 @@ __device__ __forceinline__ float norm1(f3 a) { return fabsf(a.x) + fabsf(a.y) + 
 // instruction instead of the ~12 of the correctly rounded sqrtf.  Every bound that uses it carries a relative
 // slack of at least 1e-6.
 __device__ __forceinline__ float bsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
-// max / min for the BOUNDS (never for a value of the reference's arithmetic): the hardware instruction as it is.  fmaxf()
-// makes the compiler quiet possible signalling NaNs first (a `v_max_f32 x, x` in front of every operand that comes
-// from a load, a readlane or a DPP move — a third of the kernel's v_max instructions); v_max_f32 / v_max3_f32 return
-// the other operand for a NaN exactly like fmaxf.
-__device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ float max_abs3(float a, float b, float c) {
-  float r; asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;
-}
-__device__ __forceinline__ float norm_inf(f3 a) { return max_abs3(a.x, a.y, a.z); }
+// |a|_inf.  (Issuing v_max_f32 / v_max3_f32 through inline asm — to avoid the `v_max x,x` with which the compiler quiets
+// possible signalling NaNs in front of fmaxf operands that come from loads, lane reads and DPP moves, 94 of the kernel's
+// 150 v_max — was built and measured: the asm blocks cost more in scheduling and hazard padding than the canonicalising
+// instructions do; 3.59 -> 3.98 ms.)
+__device__ __forceinline__ float norm_inf(f3 a) { return fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fabsf(a.z)); }
+__device__ __forceinline__ float max_abs3(float a, float b, float c) { return fmaxf(fmaxf(fabsf(a), fabsf(b)), fabsf(c)); }
 
 // Wave-wide reductions.  The result is the same in every lane; readfirstlane tells the compiler so
 // (otherwise everything derived from it — the candidate masks, the loops over them — is treated as
@@ -55,22 +51,43 @@ __device__ __forceinline__ float dpp(float old, float src) {
 // to lane 63) instead of six ds_bpermute round trips of ~100 cycles each: the reductions sit on the critical path
 // of every task (level 1) and the kernel is latency-sensitive at 5 waves per SIMD.  Call with all 64 lanes active.
 __device__ __forceinline__ float wave_max(float v) {
-  v = vmax(v, dpp<0x111, 0xf>(v, v));
-  v = vmax(v, dpp<0x112, 0xf>(v, v));
-  v = vmax(v, dpp<0x114, 0xf>(v, v));
-  v = vmax(v, dpp<0x118, 0xf>(v, v));
-  v = vmax(v, dpp<0x142, 0xa>(v, v));
-  v = vmax(v, dpp<0x143, 0xc>(v, v));
+  v = fmaxf(v, dpp<0x111, 0xf>(v, v));
+  v = fmaxf(v, dpp<0x112, 0xf>(v, v));
+  v = fmaxf(v, dpp<0x114, 0xf>(v, v));
+  v = fmaxf(v, dpp<0x118, 0xf>(v, v));
+  v = fmaxf(v, dpp<0x142, 0xa>(v, v));
+  v = fmaxf(v, dpp<0x143, 0xc>(v, v));
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_min(float v) {
-  v = vmin(v, dpp<0x111, 0xf>(v, v));
-  v = vmin(v, dpp<0x112, 0xf>(v, v));
-  v = vmin(v, dpp<0x114, 0xf>(v, v));
-  v = vmin(v, dpp<0x118, 0xf>(v, v));
-  v = vmin(v, dpp<0x142, 0xa>(v, v));
-  v = vmin(v, dpp<0x143, 0xc>(v, v));
+  v = fminf(v, dpp<0x111, 0xf>(v, v));
+  v = fminf(v, dpp<0x112, 0xf>(v, v));
+  v = fminf(v, dpp<0x114, 0xf>(v, v));
+  v = fminf(v, dpp<0x118, 0xf>(v, v));
+  v = fminf(v, dpp<0x142, 0xa>(v, v));
+  v = fminf(v, dpp<0x143, 0xc>(v, v));
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// The same for values that are known to be >= +0 (norms, lengths, pixel coordinates): non-negative floats order like
+// their bit patterns, and an integer max needs no NaN quieting (fmaxf makes the compiler put a `v_max x,x` in front of
+// every operand that comes out of a DPP move: twelve extra instructions per reduction).  A NaN (pattern above every
+// finite value) wins the maximum, which every caller treats as "no bound".
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dppu(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ float wave_max_pos(float f) {
+  unsigned v = __float_as_uint(f);
+  v = max(v, dppu<0x111, 0xf>(v)); v = max(v, dppu<0x112, 0xf>(v)); v = max(v, dppu<0x114, 0xf>(v));
+  v = max(v, dppu<0x118, 0xf>(v)); v = max(v, dppu<0x142, 0xa>(v)); v = max(v, dppu<0x143, 0xc>(v));
+  return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)v, 63));
+}
+__device__ __forceinline__ float wave_min_pos(float f) {
+  unsigned v = __float_as_uint(f);
+  v = min(v, dppu<0x111, 0xf>(v)); v = min(v, dppu<0x112, 0xf>(v)); v = min(v, dppu<0x114, 0xf>(v));
+  v = min(v, dppu<0x118, 0xf>(v)); v = min(v, dppu<0x142, 0xa>(v)); v = min(v, dppu<0x143, 0xc>(v));
+  return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)v, 63));
 }
 
 // Sum of the aa AA rays of a pixel in index order (final_color_total +=, kernels.cl:415-425), valid in the FIRST lane
