@@ -134,8 +134,8 @@ int rt_count_work(rt_ctx* ctx, const float rot[12], const float cam[3], const fl
  * out[6..7] = 0.
  * Meshes (n > 64, tiled kernel): out[0] = (wave, tile) visits of the primary pass, out[1] = triangles left by
  * the primary bound over those visits, out[2] = (wave, tile) visits of the shadow pass, out[3] = triangles
- * left by level 1, out[4] = level-3 point-pair calls, out[5] = their first-stage passes, out[7] = task
- * rounds per wave summed over waves.                                                                       */
+ * left by level 1, out[4] = level-3 point-pair calls, out[5] = their first-stage passes, out[6] = the longest
+ * 16x16-pixel block in s_memtime ticks (shader cycles), out[7] = task rounds per wave summed over waves.                                                                       */
 int rt_count_executed(rt_ctx* ctx, const float rot[12], const float cam[3], const float light[3],
                       float focal, uint64_t out[8]);
 
@@ -152,6 +152,12 @@ int rt_last_kernel_ms(rt_ctx* ctx, float* out_ms);
 enum { RT_TRACE_IN_SHADOW = 0, RT_TRACE_CLOSEST_HIT = 1 };
 int rt_debug_trace_rays(rt_ctx* ctx, int32_t what, const float* rays6, const float* radius_sq, int64_t nray,
                         int32_t* out_tri, float* out10);
+
+/* Diagnostic, mesh kernel (n > 64): the cost of every 16x16-pixel block of the most recent frame in s_memtime ticks
+ * (shader cycles) — the scheduling state "last frame's expensive blocks first" is built from it.  Row-major over
+ * ceil(owned_rows/16) x ceil(width/16) blocks; writes min(count, cap) values, returns the block count, or
+ * RT_E_UNSUPPORTED when the context keeps no such state (n <= 64, RT_FLAG_PLAIN_ORDER, generic kernel).          */
+int rt_debug_block_costs(rt_ctx* ctx, uint32_t* out, int32_t cap);
 
 /* On-device self test of the exact-reciprocal building block (rt_math.h rcp_newton): sweeps all 2^32
  * FP32 patterns and compares v_rcp_f32 + 1/2 Newton steps with the correctly rounded 1.0f/x.

@@ -15,3 +15,13 @@ for i in range(2):
 if len(sys.argv) > 4:
     for k, v in tr.count_executed(rot, cam, light, 1100.0 * W / 1024).items():
         print("  %-28s %d" % (k, v))
+if os.environ.get("COSTS"):
+    import numpy as np
+    tr.render(rot, cam, light, 1100.0 * W / 1024)
+    c = tr.block_costs().astype(np.float64)
+    print("blocks", c.shape, "sum %.3g ticks" % c.sum(), "max %.3g" % c.max(), "mean %.3g" % c.mean(), "blocks above max/4:", int((c > c.max() / 4).sum()))
+    ys, xs = np.unravel_index(np.argsort(c.ravel())[::-1][:12], c.shape)
+    for y, x in zip(ys, xs):
+        print("  block row %d col %d: %.3g ticks" % (y, x, c[y, x]))
+    hist, edges = np.histogram(np.log10(c.ravel() + 1), bins=12)
+    print("log10(ticks) histogram", [(round(float(e), 1), int(h)) for e, h in zip(edges, hist)])

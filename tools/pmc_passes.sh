@@ -17,5 +17,5 @@ run lds     SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_WAIT_
 run occ     SQ_WAVES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_INSTS_BRANCH SQ_ACTIVE_INST_MISC SQ_CYCLES
 run fetch   FETCH_SIZE
 run write   WRITE_SIZE
-rocprofv3 --kernel-trace --stats -d $OUT/trace --output-format csv -- $BENCH > $OUT/trace.log 2>&1 || echo "trace pass failed"
+rocprofv3 --kernel-trace --stats -d $OUT/trace --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 40 --warmup 3 --timed-only $* > $OUT/trace.log 2>&1 || echo "trace pass failed"
 echo "pmc passes done: $OUT"

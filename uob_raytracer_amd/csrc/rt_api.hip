@@ -55,6 +55,7 @@ void launch_wave(const FrameParams& P, bool cull, bool count, hipStream_t stream
 void launch_wave_prof(const FrameParams& P, hipStream_t stream);
 bool wave_kernel_supports(const FrameParams& P);
 int wave_blocks_per_cu(bool leave_room);
+int mesh_blocks_per_cu();
 
 }  // namespace uobrt
 
@@ -102,6 +103,8 @@ struct rt_ctx {
   // triangles first, then Morton order of the centroids), the original index of each triangle, and the tiles' boxes
   float4 *d_verts_m = nullptr, *d_normals_m = nullptr, *d_colors_m = nullptr, *d_tile_box = nullptr;
   int* d_orig = nullptr;
+  unsigned int *d_mesh_cost = nullptr, *d_mesh_order = nullptr;   // per 16x16-pixel block: last frame's cost, this frame's order
+  bool mesh_order_valid = false;
   // mesh kernel: per-frame candidate-tile masks (rt_kernel_mesh.hip) and the scene's bounding box for its world grid
   unsigned long long *d_screen_masks = nullptr, *d_world_masks = nullptr;
   unsigned int* d_world_occ = nullptr;
@@ -412,6 +415,12 @@ int rt_init(const rt_config* cfg, const float* vertices4, const float* normals4,
   if (n > 64 && !(cfg->flags & RT_FLAG_GENERIC_KERNEL)) {
     rc = upload_tiled_scene(c, vertices4, normals4, colors4, n);
     if (rc != RT_OK) return fail(rc);
+    if (!c->tune.plain_order) {
+      const size_t jobs = (size_t)((cfg->width + 15) / 16) * (size_t)((c->owned_rows + 15) / 16);
+      if (hipMalloc(&c->d_mesh_cost, (jobs ? jobs : 1) * 4) != hipSuccess || hipMalloc(&c->d_mesh_order, (jobs ? jobs : 1) * 4) != hipSuccess) {
+        set_error("hipMalloc failed: %s", hipGetErrorString(hipGetLastError())); return fail(RT_E_NOMEM);
+      }
+    }
   }
   *out_ctx = c;
   return RT_OK;
@@ -501,6 +510,7 @@ static void fill_params(const rt_ctx* c, const float rot[12], const float cam[3]
 static void use_tiled_scene(const rt_ctx* c, FrameParams* P) {
   P->verts = c->d_verts_m; P->normals = c->d_normals_m; P->colors = c->d_colors_m;
   P->orig = c->d_orig; P->tile_box = c->d_tile_box;
+  P->mesh_blocks = c->cus * mesh_blocks_per_cu();
 }
 
 // One frame of a single-device context into d_argb (packed rows, or global rows when out_global) on `stream`
@@ -540,6 +550,11 @@ static int launch_frame(rt_ctx* c, const float rot[12], const float cam[3], cons
     launch_wave(P, !(c->cfg.flags & RT_FLAG_NO_CULL), false, stream);
   } else if (wave_paths && !(c->cfg.flags & RT_FLAG_NO_CULL) && mesh_kernel_supports(P)) {
     use_tiled_scene(c, &P);
+    if (c->d_mesh_cost) {                   // last frame's expensive blocks first; this frame's costs make the next order
+      P.mesh_order = c->mesh_order_valid ? c->d_mesh_order : nullptr;
+      P.mesh_cost = c->d_mesh_cost; P.mesh_order_out = c->d_mesh_order;
+      c->mesh_order_valid = true;
+    }
     launch_stage_records(P, stream);        // per frame: the records hold camera-dependent terms
     launch_mesh(P, false, false, stream);
   } else {
@@ -764,6 +779,27 @@ int rt_debug_trace_rays(rt_ctx* c, int32_t what, const float* rays6, const float
   return rc;
 }
 
+int rt_debug_block_costs(rt_ctx* c, uint32_t* out, int32_t cap) {
+  if (!c || (!out && cap > 0) || cap < 0) { set_error("NULL argument"); return RT_E_INVALID; }
+  if (!c->kids.empty()) c = c->kids[0];
+  if (!c->d_mesh_cost || !c->mesh_order_valid) { set_error("rt_debug_block_costs: this context records no block costs"); return RT_E_UNSUPPORTED; }
+  DeviceGuard guard;
+  HIP_TRY(hipSetDevice(c->device));
+  const int jobs = ((c->cfg.width + 15) / 16) * ((c->owned_rows + 15) / 16);
+  if (c->timed) HIP_TRY(hipEventSynchronize(c->ev1));
+  // job id -> block: rows are numbered from the middle outwards (rt_kernel_mesh.hip), undo that here
+  std::vector<uint32_t> raw((size_t)jobs);
+  HIP_TRY(hipMemcpy(raw.data(), c->d_mesh_cost, (size_t)jobs * 4, hipMemcpyDeviceToHost));
+  const int wx = (c->cfg.width + 15) / 16, wy = (c->owned_rows + 15) / 16, mid = (wy + 1) >> 1;
+  for (int j = 0; j < jobs; ++j) {
+    const int jy = j / wx, jx = j - jy * wx;
+    const int row = (jy & 1) ? mid + (jy >> 1) : mid - 1 - (jy >> 1);
+    const int at = row * wx + jx;
+    if (at >= 0 && at < cap) out[at] = raw[(size_t)j];
+  }
+  return jobs;
+}
+
 int rt_last_kernel_ms(rt_ctx* c, float* out_ms) {
   if (!c || !out_ms) { set_error("NULL argument"); return RT_E_INVALID; }
   DeviceGuard guard;
@@ -798,6 +834,7 @@ void rt_destroy(rt_ctx* c) {
   hipFree(c->d_argb); hipFree(c->d_rgb); hipFree(c->d_counters); hipFree(c->d_records); hipFree(c->d_jobctr);
   hipFree(c->d_screen_masks); hipFree(c->d_world_masks); hipFree(c->d_world_occ);
   hipFree(c->d_heavy[0]); hipFree(c->d_heavy[1]); hipFree(c->d_heavy_flags);
+  hipFree(c->d_mesh_cost); hipFree(c->d_mesh_order);
   hipFree(c->d_verts_m); hipFree(c->d_normals_m); hipFree(c->d_colors_m); hipFree(c->d_orig); hipFree(c->d_tile_box);
   delete c;
 }

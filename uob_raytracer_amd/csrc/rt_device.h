@@ -67,6 +67,11 @@ struct FrameParams {
   int32_t heavy_factor4;              // a job is expensive above heavy_factor4 / 4 times the average job cost
   int32_t heavy_cap;
   float4* records;        // staged triangle records in HBM (8 x n float4), used when n exceeds one LDS stage
+  // mesh kernel: persistent workgroups pull 16x16-pixel blocks; last frame's expensive blocks first
+  const unsigned int* mesh_order;   // job order of this frame (nullptr: plain order)
+  unsigned int* mesh_cost;          // per block: s_memtime ticks it took this frame (nullptr: not recorded)
+  unsigned int* mesh_order_out;     // next frame's order, written by rt_mesh_order after the frame
+  int32_t mesh_blocks;              // workgroups the device holds at once
   const int* orig;        // mesh kernel: original index of every (reordered) triangle; nullptr = the order is the original
   const float4* tile_box; // mesh kernel: per 64-triangle tile, its vertices' box: lo.xyz, hi.xyz
   // mesh kernel: per-frame candidate-tile masks (rt_kernel_mesh.hip), nullptr = visit every tile

@@ -346,7 +346,7 @@ __global__ __launch_bounds__(64 * kMeshWaves) void rt_bin_shadow(const FramePara
   }
 }
 
-// Grid: x = ceil(W/16), y = ceil(owned_rows/16); block = 4 waves = 2x2 blocks of 8x8 pixels.
+// Grid: the workgroups the device holds at once (persistent, see the job loop); block = 4 waves = 2x2 blocks of 8x8 pixels.
 // COUNT: diagnostic build that also sums what the waves executed into P.counters[0..7] (rt_count_executed)
 // PROF: diagnostic build (never timed) that sums s_memtime cycles per phase over the waves instead
 #define MESH_STAMP(slot)                                                            \
@@ -366,10 +366,6 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
   float4* tile = lds;                                   // kBatch staged tiles x 4 records x kTile triangles
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
-  // workgroup rows are dispatched from the middle of the frame outwards: the last workgroups to start are the
-  // top and bottom ones, usually the cheap ones (the kernel ends when the last workgroup does)
-  const int wg_mid = ((int)gridDim.y + 1) >> 1;
-  const int wg_row = (blockIdx.y & 1) ? wg_mid + (int)(blockIdx.y >> 1) : wg_mid - 1 - (int)(blockIdx.y >> 1);
   const int wave_bytes = mesh_wave_lds_bytes(P.S > kPointSamples || P.nsph > 0);
   char* const wbase = reinterpret_cast<char*>(lds + kBatch * kSlot) + wave * wave_bytes;
   const MeshWaveLds L{reinterpret_cast<float4*>(wbase), reinterpret_cast<float4*>(wbase + 64 * 16),
@@ -381,10 +377,28 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
                                                                     kMeshWaves * wave_bytes);
   unsigned long long* smask = pmask + nwords;
   const bool bins = P.screen_masks != nullptr;
+  // Persistent workgroups: a job is one 16x16-pixel block of the frame (this workgroup's four 8x8 tasks-blocks); the
+  // blocks that look at the mesh's silhouette or stand in its shadow cost a hundred times what a wall block costs,
+  // and the frame ends when the last one does — so they are pulled from a queue, the blocks that were expensive in
+  // the context's PREVIOUS frame first (P.mesh_order, built by rt_mesh_order from the costs each job records; the
+  // first frame goes from the middle rows outwards).  No pixel depends on the order.
+  __shared__ int s_job;
+  const int wgx_n = (P.W + 15) / 16, wgy_n = (P.owned_rows + 15) / 16, n_jobs = wgx_n * wgy_n;
+  const int wg_mid = (wgy_n + 1) >> 1;
+  for (;;) {
+  __syncthreads();                                     // the previous job's LDS (and s_job) are no longer read
+  if (tid == 0) s_job = (int)atomicAdd(P.job_counter, 1u);
+  __syncthreads();
+  if (s_job >= n_jobs) break;                          // the counter only grows: every workgroup gets here
+  const int job = P.mesh_order != nullptr ? (int)P.mesh_order[s_job] : s_job;
+  const unsigned long long job_t0 = (COUNT || P.mesh_cost != nullptr) ? __builtin_amdgcn_s_memtime() : 0ull;
+  const int job_y = job / wgx_n, job_x = job - job_y * wgx_n;
+  // without an order list: rows from the middle of the frame outwards (the last to start are the top and bottom ones)
+  const int wg_row = (job_y & 1) ? wg_mid + (job_y >> 1) : wg_mid - 1 - (job_y >> 1);
   for (int w = tid; w < nwords; w += 64 * kMeshWaves) {
     unsigned long long m = (bins && !(P.mask_debug & 1)) ? 0ull : ~0ull;
     if (bins && !(P.mask_debug & 1)) {
-      const int cx = (blockIdx.x * 16) >> kScreenCellLog;
+      const int cx = (job_x * 16) >> kScreenCellLog;
       int last = -1;
       for (int r = 0; r < 16; ++r) {                      // the workgroup's 16 packed rows: global y may jump at a band edge
         const int lrr = wg_row * 16 + r;
@@ -404,7 +418,7 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
   const int ntask = (64 + PT - 1) / PT;                 // tasks per 8x8 block
   const int pt_magic = (65536 + PT - 1) / PT;           // q / PT == (q * pt_magic) >> 16 for q < 64
   BlockGeom B;
-  B.x0 = blockIdx.x * 16 + (wave & 1) * 8;
+  B.x0 = job_x * 16 + (wave & 1) * 8;
   B.lr0 = wg_row * 16 + (wave >> 1) * 8;                // waves past the frame still walk the tiles (barriers)
   B.PT = PT;
   const int GP = PT < kRngPixels ? PT : kRngPixels;
@@ -654,6 +668,7 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
         const int jr = __builtin_ctzll(rem);
         const int cj = __builtin_amdgcn_readlane(ci, jr);
         const unsigned long long gm = ngroups == kMaxGroups - 1 ? rem : (rem & ballot(ci == cj));
+        const bool one_cell = bins && (gm & ~ballot(ci == cj)) == 0ull;      // false for an overflow group over several cells
         rem &= ~gm;
         const bool in = ((gm >> lane) & 1ull) != 0ull;
         const f3 s0 = mk(rl(start.x, jr), rl(start.y, jr), rl(start.z, jr));
@@ -674,7 +689,9 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
           L.grp[4 * ngroups] = make_float4(s0.x, s0.y, s0.z, es);
           L.grp[4 * ngroups + 1] = make_float4(D0.x, D0.y, D0.z, ed);
           L.grp[4 * ngroups + 2] = make_float4(dlen_min, dlen_max, 1.002f * hbox + 2e-6f * (dlen_max + hbox), linf_l + dlen_max);
-          L.grp[4 * ngroups + 3] = make_float4(__uint_as_float((unsigned)gm), __uint_as_float((unsigned)(gm >> 32)), 0.f, 0.f);
+          // .z: the group's world cell (all its points start there), -1 for the overflow group, which holds several
+          L.grp[4 * ngroups + 3] = make_float4(__uint_as_float((unsigned)gm), __uint_as_float((unsigned)(gm >> 32)),
+                                               __int_as_float(one_cell ? cj : -1), 0.f);
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -738,6 +755,12 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
           const unsigned long long gm = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(g3.y)) << 32) |
                                         (unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(g3.x));
           if ((gm & alive) == 0ull) continue;
+          // the group's own cell has certified this whole tile clear (rt_bin_shadow): nothing to bound, nothing to test.
+          // (The workgroup visits the union of its 256 points' cells' tiles; a task that straddles a silhouette holds
+          // six groups, and most tiles of the union matter to one of them.)
+          const int gcell = __builtin_amdgcn_readfirstlane(__float_as_int(g3.z));
+          if (gcell >= 0 && !(P.mask_debug & 2) &&
+              ((P.world_masks[(size_t)gcell * nwords + (t >> 6)] >> (t & 63)) & 1ull) == 0ull) continue;
           unsigned long long Kg = casts;
           if (g0.w < 1e30f && g1.w < 1e30f) {
             const Bound tb = light_bundle_bound(T1, light, mk(g0.x, g0.y, g0.z), g0.w, mk(g1.x, g1.y, g1.z), g1.w, g2.z, g2.x, g2.y,
@@ -754,7 +777,7 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
         if (ballot(lit && !blocked) == 0ull) { task_blocked = true; return; }
       }
       MESH_STAMP(5)
-      if (COUNT) { xw[2]++; xw[3] += __popcll(K); xw[6] += (K == casts && __popcll(casts) > 32) ? 1 : 0; }
+      if (COUNT) { xw[2]++; xw[3] += __popcll(K); }
       if (K == 0ull) return;
       unsigned long long need = 0ull;                              // level 2, lane = surface point; bit = tile triangle
       // with one or two samples per point the bound costs more than the samples: test every candidate
@@ -907,19 +930,49 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
     }
   }
   MESH_STAMP(7)
+  if (COUNT) xw[7] += ntask;
+  {
+    const int x = B.x0 + (lane & 7);
+    const int lr = B.lr0 + (lane >> 3);
+    if (!COUNT && !PROF && lr < P.owned_rows && x < P.W) {      // the counting pass has no framebuffer
+      const f3 c = mk(div_count(outc.x, aa, P.inv_aa), div_count(outc.y, aa, P.inv_aa), div_count(outc.z, aa, P.inv_aa));
+      const size_t o = (size_t)(P.out_global ? band_global_row(lr, P.band_rows, P.band_index, P.band_count) : lr) * P.W + x;
+      P.out_argb[o] = pack_argb(c);
+      if (P.out_rgb) P.out_rgb[o] = make_float4(c.x, c.y, c.z, 1.0f);
+    }
+  }
+  if (COUNT && tid == 0) atomicMax(&P.counters[6], __builtin_amdgcn_s_memtime() - job_t0);   // the longest block, in ticks
+  if (P.mesh_cost != nullptr && tid == 0) {
+    const unsigned long long dt = __builtin_amdgcn_s_memtime() - job_t0;
+    P.mesh_cost[job] = dt > 0xffffffffull ? 0xffffffffu : (unsigned int)dt;
+  }
+  }                                                    // ---- end of the job loop ----------------------------------
   if (PROF) { if (lane == 0) for (int q = 0; q < 8; ++q) atomicAdd(&P.counters[q], xw[q]); return; }
   if (COUNT) {
-    xw[7] = ntask;
     if (lane == 0) for (int q = 0; q < 8; ++q) if (xw[q] && q != 6) atomicAdd(&P.counters[q], xw[q]);
-    if (lane == 0) atomicMax(&P.counters[6], xw[3]);       // heaviest wave: level-1 survivors
   }
-  const int x = B.x0 + (lane & 7);
-  const int lr = B.lr0 + (lane >> 3);
-  if (!COUNT && !PROF && lr < P.owned_rows && x < P.W) {      // the counting pass has no framebuffer
-    const f3 c = mk(div_count(outc.x, aa, P.inv_aa), div_count(outc.y, aa, P.inv_aa), div_count(outc.z, aa, P.inv_aa));
-    const size_t o = (size_t)(P.out_global ? band_global_row(lr, P.band_rows, P.band_index, P.band_count) : lr) * P.W + x;
-    P.out_argb[o] = pack_argb(c);
-    if (P.out_rgb) P.out_rgb[o] = make_float4(c.x, c.y, c.z, 1.0f);
+}
+
+// Next frame's job order from this frame's costs: expensive blocks first (64 linear cost classes; inside a class the
+// order is whatever the atomics make it — no pixel depends on it).  One workgroup.
+__global__ __launch_bounds__(1024) void rt_mesh_order(const unsigned int* cost, unsigned int* order, int n_jobs) {
+  __shared__ unsigned int smax, hist[64], base[64];
+  const int tid = threadIdx.x;
+  if (tid == 0) smax = 0u;
+  if (tid < 64) hist[tid] = 0u;
+  __syncthreads();
+  unsigned int m = 0u;
+  for (int i = tid; i < n_jobs; i += 1024) m = cost[i] > m ? cost[i] : m;
+  atomicMax(&smax, m);
+  __syncthreads();
+  const unsigned long long scale = (unsigned long long)smax + 1ull;
+  for (int i = tid; i < n_jobs; i += 1024) atomicAdd(&hist[63 - (int)((unsigned long long)cost[i] * 64ull / scale)], 1u);
+  __syncthreads();
+  if (tid == 0) { unsigned int at = 0u; for (int b = 0; b < 64; ++b) { base[b] = at; at += hist[b]; } }
+  __syncthreads();
+  for (int i = tid; i < n_jobs; i += 1024) {
+    const int b = 63 - (int)((unsigned long long)cost[i] * 64ull / scale);
+    order[atomicAdd(&base[b], 1u)] = (unsigned int)i;
   }
 }
 
@@ -944,11 +997,18 @@ void launch_mesh(const FrameParams& P, bool count, bool prof, hipStream_t stream
     hipLaunchKernelGGL(rt_bin_primary, dim3((ntiles + kMeshWaves - 1) / kMeshWaves, P.scy), block, 0, stream, P);
     hipLaunchKernelGGL(rt_bin_shadow, dim3((ntiles + kMeshWaves - 1) / kMeshWaves, P.grid_g / 4, P.grid_g / 4), block, 0, stream, P);
   }
-  const dim3 grid((P.W + 15) / 16, (P.owned_rows + 15) / 16);
+  const int n_jobs = ((P.W + 15) / 16) * ((P.owned_rows + 15) / 16);
+  const int resident = P.mesh_blocks > 0 ? P.mesh_blocks : 256 * RT_MESH_MIN_BLOCKS;
+  const dim3 grid(n_jobs < resident ? (n_jobs > 0 ? n_jobs : 1) : resident);
+  hipMemsetAsync(P.job_counter, 0, sizeof(unsigned int), stream);
   const size_t lds_bytes = kBatch * kSlot * sizeof(float4) + kMeshWaves * (size_t)mesh_wave_lds_bytes(P.S > kPointSamples || P.nsph > 0) + 2 * (size_t)nwords * 8;
   if (count && prof) hipLaunchKernelGGL((rt_draw_mesh<false, true>), grid, block, lds_bytes, stream, P);
   else if (count) hipLaunchKernelGGL((rt_draw_mesh<true>), grid, block, lds_bytes, stream, P);
   else hipLaunchKernelGGL((rt_draw_mesh<false>), grid, block, lds_bytes, stream, P);
+  if (!count && P.mesh_cost != nullptr && P.mesh_order_out != nullptr)
+    hipLaunchKernelGGL(rt_mesh_order, dim3(1), dim3(1024), 0, stream, P.mesh_cost, P.mesh_order_out, n_jobs);
 }
+
+int mesh_blocks_per_cu() { return RT_MESH_MIN_BLOCKS; }
 
 }  // namespace uobrt

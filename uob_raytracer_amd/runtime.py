@@ -17,7 +17,7 @@ EXPORTS = (
     "rt_abi_version", "rt_last_error", "rt_config_default", "rt_config_owned_rows", "rt_init", "rt_render",
     "rt_render_device", "rt_count_work", "rt_count_executed", "rt_last_kernel_ms", "rt_destroy", "rt_scene_cornell_box",
     "rt_scene_load_obj", "rt_scene_load_obj_ex", "rt_triangle_compute_normal", "rt_scene_pack", "rt_rotation_matrix",
-    "rt_selftest_rcp", "rt_debug_trace_rays",
+    "rt_selftest_rcp", "rt_debug_trace_rays", "rt_debug_block_costs",
 )
 
 _lib = None
@@ -54,6 +54,7 @@ def lib():
         L.rt_scene_load_obj.argtypes = [C.c_char_p, C.POINTER(abi.RtTriangle), C.c_int32]
         L.rt_scene_load_obj_ex.argtypes = [C.c_char_p, fp, C.c_float, fp, C.POINTER(abi.RtTriangle), C.c_int32]
         L.rt_debug_trace_rays.argtypes = [vp, C.c_int32, fp, fp, C.c_int64, C.POINTER(C.c_int32), fp]
+        L.rt_debug_block_costs.argtypes = [vp, C.POINTER(C.c_uint32), C.c_int32]
         L.rt_triangle_compute_normal.argtypes = [C.POINTER(abi.RtTriangle)]
         L.rt_triangle_compute_normal.restype = None
         L.rt_scene_pack.argtypes = [C.POINTER(abi.RtTriangle), C.c_int32, fp, fp, fp]
@@ -205,7 +206,7 @@ class RayTracer:
         _check(lib().rt_count_executed(self._h, _fp(rot), _fp(cam), _fp(light), C.c_float(focal), out))
         if self.n_triangles > 64:      # tiled mesh kernel
             keys = ("primary_tile_visits", "primary_bound_survivors", "shadow_tile_visits", "level1_survivors",
-                    "level3_pair_calls", "level3_stage1_iterations", "shadow_visits_nothing_culled", "wave_task_rounds")
+                    "level3_pair_calls", "level3_stage1_iterations", "longest_block_ticks", "wave_task_rounds")
         else:
             keys = ("surface_points", "stage1_wave_iterations", "stage2_wave_iterations", "sphere_wave_evaluations",
                     "culled_pairs", "tasks_resolved_whole", "sampled_points_fully_lit", "sampled_points_fully_blocked")
@@ -228,6 +229,13 @@ class RayTracer:
         _check(lib().rt_debug_trace_rays(self._h, abi.RT_TRACE_CLOSEST_HIT, _fp(rays), None, rays.shape[0],
                                          tri.ctypes.data_as(C.POINTER(C.c_int32)), _fp(out)))
         return tri, out
+
+    def block_costs(self):
+        """Mesh kernel: s_memtime ticks of every 16x16-pixel block of the last frame, [rows/16, W/16] (rt_debug_block_costs)."""
+        n = _check(lib().rt_debug_block_costs(self._h, None, 0))
+        out = np.zeros(n, np.uint32)
+        _check(lib().rt_debug_block_costs(self._h, out.ctypes.data_as(C.POINTER(C.c_uint32)), n))
+        return out.reshape((self.rows + 15) // 16, (self.width + 15) // 16)
 
     def last_kernel_ms(self):
         ms = C.c_float()
