@@ -6,14 +6,15 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["UOB_RT_PHASE_PROFILE"] = "1"
 from uob_raytracer_amd import abi, runtime as rt
-cfg = abi.make_config(width=4096, height=4096, aa_x=4, aa_y=2, shadow_samples=64)
+bc = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+cfg = abi.make_config(width=4096, height=4096, aa_x=4, aa_y=2, shadow_samples=64, band_rows=32 if bc > 1 else 0, band_index=0, band_count=bc)
 tr = rt.RayTracer(cfg, rt.Scene.cornell_box())
 rot, cam, light = rt.rotation_matrix(0, 0), [0, 0, -3.2], [0, -0.5, -0.7]
 out = (C.c_uint64 * 8)()
 rt._check(rt.lib().rt_count_executed(tr._h, rt._fp(rot), rt._fp(__import__("numpy").array(cam, "f4")),
                                       rt._fp(__import__("numpy").array(light, "f4")), C.c_float(17600.0), out))
-names = ["staging", "primary+bounce", "light setup + level 1", "level 2", "xorshift streams", "level 3 sample tests",
-         "shading + AA sum", "-"]
+names = ["job set-up (primary bounds)", "primary+bounce", "light setup + level 1", "level 2", "xorshift streams", "level 3 sample tests",
+         "shading + AA sum (dead code in this build)", "hand-out wait (+ staging once)"]
 tot = sum(out)
 for n, v in zip(names, out):
     print("%-26s %14d  %5.1f %%" % (n, v, 100.0 * v / max(tot, 1)))

@@ -41,8 +41,8 @@
 #ifndef RT_OPT_TASKSPH
 #define RT_OPT_TASKSPH 1
 #endif
-#ifndef RT_OPT_PAIR
-#define RT_OPT_PAIR 1
+#ifndef RT_CHUNK
+#define RT_CHUNK 4          // jobs per hand-out while the queue is long (2: 3.58 ms, 4: 3.50, 8: 3.64 on the headline frame)
 #endif
 
 namespace uobrt {
@@ -334,11 +334,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
     if (pjobs != 0u) heavy_thr = (unsigned long long)P.heavy_factor4 * (psum / pjobs) / 4ull;    // per TASK
   }
   bool phase_a = n_heavy != 0u;
-#if RT_OPT_PAIR
-  int next_job = -1;                                    // second job of the last hand-out, still to do
-  const int pair_limit = P.njobs - 8 * (int)gridDim.x * kWavesPerBlock;   // pairs until ~8 jobs per wave are left
-  bool pair_ok = pair_limit > 0;
-#endif
+  // Several jobs per hand-out while the queue is long (a hand-out is a returning device-scope atomic that stalls its
+  // wave for microseconds), fewer as it runs out, single jobs over the last stretch, where balance matters more.
+  const int per_wave = 8 * (int)gridDim.x * kWavesPerBlock;
+  int next_job = -1, chunk_left = 0;                    // the rest of the last hand-out, still to do
+  int chunk = P.njobs > 2 * per_wave ? RT_CHUNK : (P.njobs > per_wave ? 2 : 1);      // size of the next hand-out
   for (;;) {
   int job = 0;
   const int jt = P.job_tasks;                 // tasks of this hand-out
@@ -349,25 +349,19 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
     job = (int)P.heavy_prev[unit];
     if (job < 0 || job >= P.njobs) continue;
   } else {
-#if RT_OPT_PAIR
-    // two jobs per hand-out while the queue is long (a hand-out stalls its wave for microseconds: a returning
-    // device-scope atomic), single jobs over the last stretch, where balance matters more
-    if (next_job >= 0) {
-      job = next_job; next_job = -1;
+    if (chunk_left > 0) {
+      job = next_job; next_job += kJobHeads; --chunk_left;
     } else {
-      const bool two = pair_ok;
-      if (lane == 0) job = (int)atomicAdd(P.job_counter + head * kJobHeadStride, two ? 2u : 1u);
+      if (lane == 0) job = (int)atomicAdd(P.job_counter + head * kJobHeadStride, (unsigned int)chunk);
       job = __builtin_amdgcn_readfirstlane(job) * kJobHeads + head;
-      if (two) {
-        if (job + kJobHeads < P.njobs) next_job = job + kJobHeads;
-        if (job + kJobHeads >= pair_limit) pair_ok = false;
-      }
+      next_job = job + kJobHeads; chunk_left = chunk - 1;
+      // what this head has left decides the next hand-out: RT_CHUNK jobs while more than ~16 per wave remain in all,
+      // two while more than ~8, then one
+      const int left = P.njobs - next_job;
+      chunk = left > 2 * per_wave ? RT_CHUNK : (left > per_wave ? 2 : 1);
     }
-#else
-    if (lane == 0) job = (int)atomicAdd(P.job_counter + head * kJobHeadStride, 1u);
-    job = __builtin_amdgcn_readfirstlane(job) * kJobHeads + head;
-#endif
     if (job >= P.njobs) {
+      chunk_left = 0;
       bool found = false;
       while (!found && ++heads_done < kJobHeads) {
         head = head + 1 == kJobHeads ? 0 : head + 1;
@@ -379,6 +373,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
     }
     if (n_heavy != 0u && P.heavy_flags[job] >= P.heavy_gen) continue;     // listed: taken care of by phase A
   }
+  RT_STAMP(7)                               // 7: waiting for the hand-out (PROF builds)
   const unsigned long long job_t0 = lpt ? __builtin_amdgcn_s_memtime() : 0ull;
   // Rows are handed out from the middle of the rank's rows outwards: segments differ 10x in cost, and the kernel
   // ends when the last job does, so the last jobs should be cheap ones — the top and bottom rows of a view
@@ -416,6 +411,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
       sph_job = ballot(sphere_bundle_maybe(P, mk(P.cam[0], P.cam[1], P.cam[2]), 0.0f, duc, bsqrt(dot3(duc, duc)),
                                            1.0001f * bsqrt(dot3(eu, eu)), false)) != 0ull;
   }
+  RT_STAMP(0)                               // 0: job set-up (primary-ray bounds of the job)
   for (int k = 0; k < jt; ++k) {
     const int lnA = opaque(lane);
     // ---- phase 1: 64 primary rays, lnA = (pixel, AA sample) -----------------------------------------
