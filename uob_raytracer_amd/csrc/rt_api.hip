@@ -417,7 +417,8 @@ int rt_init(const rt_config* cfg, const float* vertices4, const float* normals4,
     if (rc != RT_OK) return fail(rc);
     if (!c->tune.plain_order) {
       const size_t jobs = (size_t)((cfg->width + 15) / 16) * (size_t)((c->owned_rows + 15) / 16);
-      if (hipMalloc(&c->d_mesh_cost, (jobs ? jobs : 1) * 4) != hipSuccess || hipMalloc(&c->d_mesh_order, (jobs ? jobs : 1) * 4) != hipSuccess) {
+      // order list: up to four entries per block, + its length in the word behind it
+      if (hipMalloc(&c->d_mesh_cost, (jobs ? jobs : 1) * 4) != hipSuccess || hipMalloc(&c->d_mesh_order, (4 * (jobs ? jobs : 1) + 1) * 4) != hipSuccess) {
         set_error("hipMalloc failed: %s", hipGetErrorString(hipGetLastError())); return fail(RT_E_NOMEM);
       }
     }
@@ -553,6 +554,7 @@ static int launch_frame(rt_ctx* c, const float rot[12], const float cam[3], cons
     if (c->d_mesh_cost) {                   // last frame's expensive blocks first; this frame's costs make the next order
       P.mesh_order = c->mesh_order_valid ? c->d_mesh_order : nullptr;
       P.mesh_cost = c->d_mesh_cost; P.mesh_order_out = c->d_mesh_order;
+      P.mesh_queue_len = c->d_mesh_order + 4 * (size_t)((c->cfg.width + 15) / 16) * (size_t)((c->owned_rows + 15) / 16);
       c->mesh_order_valid = true;
     }
     launch_stage_records(P, stream);        // per frame: the records hold camera-dependent terms

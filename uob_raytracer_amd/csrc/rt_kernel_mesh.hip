@@ -376,6 +376,11 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
   unsigned long long* pmask = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(lds + kBatch * kSlot) +
                                                                     kMeshWaves * wave_bytes);
   unsigned long long* smask = pmask + nwords;
+  // cooperative blocks (below): per lane, what each of the four waves found in its share of the tiles
+  struct CoopHit { float t, u, v; int best, orig; };
+  CoopHit* const coop_hit = reinterpret_cast<CoopHit*>(smask + nwords);                       // [kMeshWaves][64]
+  unsigned long long* const coop_sh = reinterpret_cast<unsigned long long*>(coop_hit + kMeshWaves * 64);   // [kMeshWaves][64] blocked samples
+  unsigned int* const coop_fl = reinterpret_cast<unsigned int*>(coop_sh + kMeshWaves * 64);  // [kMeshWaves][64] bit 0 blocked, bit 1 task_blocked
   const bool bins = P.screen_masks != nullptr;
   // Persistent workgroups: a job is one 16x16-pixel block of the frame (this workgroup's four 8x8 tasks-blocks); the
   // blocks that look at the mesh's silhouette or stand in its shadow cost a hundred times what a wall block costs,
@@ -384,13 +389,22 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
   // first frame goes from the middle rows outwards).  No pixel depends on the order.
   __shared__ int s_job;
   const int wgx_n = (P.W + 15) / 16, wgy_n = (P.owned_rows + 15) / 16, n_jobs = wgx_n * wgy_n;
+  const int n_queue = P.mesh_order != nullptr ? (int)P.mesh_queue_len[0] : n_jobs;
   const int wg_mid = (wgy_n + 1) >> 1;
   for (;;) {
   __syncthreads();                                     // the previous job's LDS (and s_job) are no longer read
   if (tid == 0) s_job = (int)atomicAdd(P.job_counter, 1u);
   __syncthreads();
-  if (s_job >= n_jobs) break;                          // the counter only grows: every workgroup gets here
-  const int job = P.mesh_order != nullptr ? (int)P.mesh_order[s_job] : s_job;
+  if (s_job >= n_queue) break;                         // the counter only grows: every workgroup gets here
+  // An entry of the order list is (block << 3) | (cooperative << 2) | sub-block.  A block that was VERY expensive in the
+  // previous frame comes as four cooperative entries, one per 8x8 sub-block: the four waves then work on the SAME 64
+  // pixels and share the TILES (of every staged batch of four, wave w takes tile w), merging what they found per lane
+  // through LDS — closest hit: smallest (t, original index); shadows: OR of the blocked-sample masks.  The longest
+  // unit of work is then a quarter of a sub-block's tiles instead of a whole block's.
+  const unsigned int entry = P.mesh_order != nullptr ? P.mesh_order[s_job] : ((unsigned int)s_job << 3);
+  const int job = (int)(entry >> 3);
+  const bool coop = (entry & 4u) != 0u;
+  const int coop_q = (int)(entry & 3u);
   const unsigned long long job_t0 = (COUNT || P.mesh_cost != nullptr) ? __builtin_amdgcn_s_memtime() : 0ull;
   const int job_y = job / wgx_n, job_x = job - job_y * wgx_n;
   // without an order list: rows from the middle of the frame outwards (the last to start are the top and bottom ones)
@@ -418,8 +432,9 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
   const int ntask = (64 + PT - 1) / PT;                 // tasks per 8x8 block
   const int pt_magic = (65536 + PT - 1) / PT;           // q / PT == (q * pt_magic) >> 16 for q < 64
   BlockGeom B;
-  B.x0 = job_x * 16 + (wave & 1) * 8;
-  B.lr0 = wg_row * 16 + (wave >> 1) * 8;                // waves past the frame still walk the tiles (barriers)
+  const int sub = coop ? coop_q : wave;                 // the 8x8 sub-block this wave renders
+  B.x0 = job_x * 16 + (sub & 1) * 8;
+  B.lr0 = wg_row * 16 + (sub >> 1) * 8;                 // waves past the frame still walk the tiles (barriers)
   B.PT = PT;
   const int GP = PT < kRngPixels ? PT : kRngPixels;
   const int GL = GP * aa;
@@ -534,9 +549,21 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
         MESH_STAMP(2)
         load_batch(t0, t1, t2, t3, cnt, true);
         MESH_STAMP(1)
-        for (int sl = 0; sl < cnt; ++sl) primary_tile(sl == 0 ? t0 : sl == 1 ? t1 : sl == 2 ? t2 : t3, tile + sl * kSlot);
+        for (int sl = 0; sl < cnt; ++sl)
+          if (!coop || sl == wave) primary_tile(sl == 0 ? t0 : sl == 1 ? t1 : sl == 2 ? t2 : t3, tile + sl * kSlot);
         if (cnt < kBatch) break;
       }
+    }
+    if (coop) {                                         // closest hit over all four waves' tiles: smallest (t, original index)
+      coop_hit[wave * 64 + lane] = CoopHit{current_t, bu, bv, best, best_o};
+      __syncthreads();
+      for (int w = 0; w < kMeshWaves; ++w) {
+        const CoopHit h = coop_hit[w * 64 + lane];
+        if (h.best >= 0 && (best < 0 || h.t < current_t || (h.t == current_t && h.orig < best_o))) {
+          current_t = h.t; bu = h.u; bv = h.v; best = h.best; best_o = h.orig;
+        }
+      }
+      __syncthreads();
     }
     MESH_STAMP(2)
     bool lit = false, secondary = false;
@@ -877,9 +904,22 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
         MESH_STAMP(7)
         load_batch(t0, t1, t2, t3, cnt, false);
         MESH_STAMP(4)
-        for (int sl = 0; sl < cnt; ++sl) shadow_tile(sl == 0 ? t0 : sl == 1 ? t1 : sl == 2 ? t2 : t3, tile + sl * kSlot);
+        for (int sl = 0; sl < cnt; ++sl)
+          if (!coop || sl == wave) shadow_tile(sl == 0 ? t0 : sl == 1 ? t1 : sl == 2 ? t2 : t3, tile + sl * kSlot);
         if (cnt < kBatch) break;
       }
+    }
+    if (coop) {                                         // any-hit over all four waves' tiles: OR of what each wave found
+      coop_sh[wave * 64 + lane] = my_sh;
+      coop_fl[wave * 64 + lane] = (blocked ? 1u : 0u) | (task_blocked ? 2u : 0u);
+      __syncthreads();
+      for (int w = 0; w < kMeshWaves; ++w) {
+        my_sh |= coop_sh[w * 64 + lane];
+        const unsigned int f = coop_fl[w * 64 + lane];
+        blocked = blocked || (f & 1u) != 0u;
+        task_blocked = task_blocked || (f & 2u) != 0u;
+      }
+      __syncthreads();
     }
     // shadow-casting spheres (kernels.cl:278-307) for the points whose rays can reach one
     {
@@ -934,7 +974,7 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
   {
     const int x = B.x0 + (lane & 7);
     const int lr = B.lr0 + (lane >> 3);
-    if (!COUNT && !PROF && lr < P.owned_rows && x < P.W) {      // the counting pass has no framebuffer
+    if (!COUNT && !PROF && (!coop || wave == 0) && lr < P.owned_rows && x < P.W) {      // the counting pass has no framebuffer
       const f3 c = mk(div_count(outc.x, aa, P.inv_aa), div_count(outc.y, aa, P.inv_aa), div_count(outc.z, aa, P.inv_aa));
       const size_t o = (size_t)(P.out_global ? band_global_row(lr, P.band_rows, P.band_index, P.band_count) : lr) * P.W + x;
       P.out_argb[o] = pack_argb(c);
@@ -944,7 +984,10 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
   if (COUNT && tid == 0) atomicMax(&P.counters[6], __builtin_amdgcn_s_memtime() - job_t0);   // the longest block, in ticks
   if (P.mesh_cost != nullptr && tid == 0) {
     const unsigned long long dt = __builtin_amdgcn_s_memtime() - job_t0;
-    P.mesh_cost[job] = dt > 0xffffffffull ? 0xffffffffu : (unsigned int)dt;
+    // zeroed per frame.  A cooperative sub-block job counts four-fold (what it would have taken one wave): the block
+    // then stays above the threshold that made it cooperative instead of alternating between the two forms.
+    const unsigned long long d4 = coop ? 4ull * dt : dt;
+    atomicAdd(&P.mesh_cost[job], d4 > 0x3fffffffull ? 0x3fffffffu : (unsigned int)d4);
   }
   }                                                    // ---- end of the job loop ----------------------------------
   if (PROF) { if (lane == 0) for (int q = 0; q < 8; ++q) atomicAdd(&P.counters[q], xw[q]); return; }
@@ -954,25 +997,41 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
 }
 
 // Next frame's job order from this frame's costs: expensive blocks first (64 linear cost classes; inside a class the
-// order is whatever the atomics make it — no pixel depends on it).  One workgroup.
-__global__ __launch_bounds__(1024) void rt_mesh_order(const unsigned int* cost, unsigned int* order, int n_jobs) {
+// order is whatever the atomics make it — no pixel depends on it); a block that cost more than 8x the mean (and more than
+// a quarter of the dearest) is entered as four cooperative sub-block jobs.  One workgroup.
+__global__ __launch_bounds__(1024) void rt_mesh_order(const unsigned int* cost, unsigned int* order, unsigned int* queue_len, int n_jobs) {
   __shared__ unsigned int smax, hist[64], base[64];
+  __shared__ unsigned long long ssum;
   const int tid = threadIdx.x;
-  if (tid == 0) smax = 0u;
+  if (tid == 0) { smax = 0u; ssum = 0ull; }
   if (tid < 64) hist[tid] = 0u;
   __syncthreads();
   unsigned int m = 0u;
-  for (int i = tid; i < n_jobs; i += 1024) m = cost[i] > m ? cost[i] : m;
+  unsigned long long sum = 0ull;
+  for (int i = tid; i < n_jobs; i += 1024) { m = cost[i] > m ? cost[i] : m; sum += cost[i]; }
   atomicMax(&smax, m);
+  atomicAdd(&ssum, sum);
   __syncthreads();
   const unsigned long long scale = (unsigned long long)smax + 1ull;
-  for (int i = tid; i < n_jobs; i += 1024) atomicAdd(&hist[63 - (int)((unsigned long long)cost[i] * 64ull / scale)], 1u);
+  const unsigned long long heavy = 8ull * (ssum / (unsigned long long)(n_jobs > 0 ? n_jobs : 1)) > (unsigned long long)smax / 4ull
+                                       ? 8ull * (ssum / (unsigned long long)(n_jobs > 0 ? n_jobs : 1)) : (unsigned long long)smax / 4ull;
+  for (int i = tid; i < n_jobs; i += 1024)
+    atomicAdd(&hist[63 - (int)((unsigned long long)cost[i] * 64ull / scale)], (unsigned long long)cost[i] > heavy ? 4u : 1u);
   __syncthreads();
-  if (tid == 0) { unsigned int at = 0u; for (int b = 0; b < 64; ++b) { base[b] = at; at += hist[b]; } }
+  if (tid == 0) {
+    unsigned int at = 0u;
+    for (int b = 0; b < 64; ++b) { base[b] = at; at += hist[b]; }
+    queue_len[0] = at;
+  }
   __syncthreads();
   for (int i = tid; i < n_jobs; i += 1024) {
     const int b = 63 - (int)((unsigned long long)cost[i] * 64ull / scale);
-    order[atomicAdd(&base[b], 1u)] = (unsigned int)i;
+    if ((unsigned long long)cost[i] > heavy) {
+      const unsigned int at = atomicAdd(&base[b], 4u);
+      for (unsigned int q = 0; q < 4u; ++q) order[at + q] = ((unsigned int)i << 3) | 4u | q;
+    } else {
+      order[atomicAdd(&base[b], 1u)] = (unsigned int)i << 3;
+    }
   }
 }
 
@@ -1001,12 +1060,14 @@ void launch_mesh(const FrameParams& P, bool count, bool prof, hipStream_t stream
   const int resident = P.mesh_blocks > 0 ? P.mesh_blocks : 256 * RT_MESH_MIN_BLOCKS;
   const dim3 grid(n_jobs < resident ? (n_jobs > 0 ? n_jobs : 1) : resident);
   hipMemsetAsync(P.job_counter, 0, sizeof(unsigned int), stream);
-  const size_t lds_bytes = kBatch * kSlot * sizeof(float4) + kMeshWaves * (size_t)mesh_wave_lds_bytes(P.S > kPointSamples || P.nsph > 0) + 2 * (size_t)nwords * 8;
+  const size_t lds_bytes = kBatch * kSlot * sizeof(float4) + kMeshWaves * (size_t)mesh_wave_lds_bytes(P.S > kPointSamples || P.nsph > 0) + 2 * (size_t)nwords * 8 +
+                           kMeshWaves * 64 * (20 + 8 + 4);          // + the cooperative blocks' merge area
+  if (!count && P.mesh_cost != nullptr) hipMemsetAsync(P.mesh_cost, 0, (size_t)n_jobs * 4, stream);
   if (count && prof) hipLaunchKernelGGL((rt_draw_mesh<false, true>), grid, block, lds_bytes, stream, P);
   else if (count) hipLaunchKernelGGL((rt_draw_mesh<true>), grid, block, lds_bytes, stream, P);
   else hipLaunchKernelGGL((rt_draw_mesh<false>), grid, block, lds_bytes, stream, P);
   if (!count && P.mesh_cost != nullptr && P.mesh_order_out != nullptr)
-    hipLaunchKernelGGL(rt_mesh_order, dim3(1), dim3(1024), 0, stream, P.mesh_cost, P.mesh_order_out, n_jobs);
+    hipLaunchKernelGGL(rt_mesh_order, dim3(1), dim3(1024), 0, stream, P.mesh_cost, P.mesh_order_out, P.mesh_queue_len, n_jobs);
 }
 
 int mesh_blocks_per_cu() { return RT_MESH_MIN_BLOCKS; }
