@@ -99,3 +99,42 @@ def test_tile_masks_never_change_a_pixel(case, scene, tmp_path):
     bad = np.argwhere(a0 != a1)
     assert bad.size == 0, "tile masks changed %d pixels, first at %s" % (len(bad), bad[0])
     assert np.array_equal(f0.view(np.uint32), f1.view(np.uint32))
+
+
+@pytest.mark.parametrize("coop_all", [False, True])
+@pytest.mark.parametrize("case", range(5))
+def test_frames_in_sequence_equal_the_first(case, coop_all, scene, oracle, tmp_path, monkeypatch):
+    """The mesh kernel carries scheduling state from frame to frame: last frame's expensive 16x16-pixel blocks go first,
+    the dearest ones as four COOPERATIVE sub-block jobs (the four waves share the tiles and merge per lane through LDS).
+    No pixel may depend on it: five frames of one context — with UOB_RT_MASK_DEBUG=8 every block of frames 2.. is
+    cooperative — against the CPU oracle, bit for bit."""
+    if coop_all:
+        monkeypatch.setenv("UOB_RT_MASK_DEBUG", "8")          # read once, in rt_init
+    path = str(tmp_path / "mesh.obj")
+    meshgen.write_sphere_obj(path, [24, 40, 12, 30, 60][case], [16, 30, 9, 20, 40][case])
+    both = scene + rt.Scene.load_obj(path)
+    kw = [dict(width=96, height=80, aa_x=1, aa_y=1, shadow_samples=1, spheres=()),
+          dict(width=80, height=64, aa_x=2, aa_y=2, shadow_samples=16, light_spread=0.2),
+          dict(width=64, height=48, aa_x=3, aa_y=3, shadow_samples=5),
+          dict(width=72, height=56, aa_x=2, aa_y=1, shadow_samples=100, max_bounces=4),
+          dict(width=128, height=112, aa_x=1, aa_y=1, shadow_samples=2, band_rows=16, band_index=1, band_count=2)][case]
+    cfg = abi.make_config(**kw)
+    v, n, c = both.packed()
+    tr = rt.RayTracer(cfg, both)
+    poses = [(0.0, 0.0, [0.0, 0.0, -3.2], [0.0, -0.5, -0.7]), (0.0, 0.0, [0.0, 0.0, -3.2], [0.0, -0.5, -0.7]),
+             (0.2, 0.1, [0.2, 0.1, -2.8], [0.2, -0.6, -0.4]), (0.2, 0.1, [0.2, 0.1, -2.8], [0.2, -0.6, -0.4]),
+             (0.0, 0.0, [0.0, 0.0, -3.2], [0.0, -0.5, -0.7])]
+    wants = {}
+    for k, (yaw, pitch, cam, light) in enumerate(poses):
+        rot = rt.rotation_matrix(yaw, pitch)
+        argb, rgb = tr.render(rot, cam, light, focal_for(cfg), want_rgb=True)
+        key = (yaw, pitch)
+        if key not in wants:
+            wants[key] = oracle.render(cfg, v, n, c, rot, cam, light, focal_for(cfg))
+        o_argb, o_rgb = wants[key]
+        bad = np.argwhere(argb.ravel() != o_argb)
+        assert bad.size == 0, "frame %d: %d pixels differ, first %s" % (k, len(bad), bad[0])
+        assert np.array_equal(rgb[..., :3].reshape(-1, 3).view(np.uint32), o_rgb.view(np.uint32))
+    costs = tr.block_costs()
+    assert costs.shape == ((tr.rows + 15) // 16, (cfg.width + 15) // 16) and (costs > 0).all()
+    tr.close()

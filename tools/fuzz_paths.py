@@ -19,6 +19,20 @@ from uob_raytracer_amd import abi, meshgen, runtime as rt
 from test_gpu_cull import _random_scene, _render
 
 
+def coop_frames_equal(kw, scene, rot, cam, light, focal, ref):
+    """Mesh kernel: three frames of ONE context, every block of frames 2 and 3 rendered as four cooperative sub-block jobs
+    (UOB_RT_MASK_DEBUG=8, read once in rt_init): the last frame must equal the single-frame result."""
+    os.environ["UOB_RT_MASK_DEBUG"] = "8"
+    try:
+        tr = rt.RayTracer(abi.make_config(**kw), scene)
+    finally:
+        del os.environ["UOB_RT_MASK_DEBUG"]
+    for _ in range(3):
+        a, f = tr.render(rot, cam, light, focal, want_rgb=True)
+    tr.close()
+    return np.array_equal(a, ref[0]) and np.array_equal(f.view(np.uint32), ref[1].view(np.uint32))
+
+
 def sphere_table(rng):
     k = int(rng.integers(0, 4))
     out = []
@@ -60,6 +74,11 @@ def one_case(seed):
         elif not (np.array_equal(a, ref[0]) and np.array_equal(f.view(np.uint32), ref[1].view(np.uint32))):
             bad = np.argwhere(a != ref[0])
             print("MISMATCH seed %d flags %d: %d pixels, first %s; n=%d kw=%s" % (seed, fl, len(bad), bad[:1].tolist(), len(scene), kw), flush=True)
+            return False
+    if len(scene) > 64 and kw["aa_x"] * kw["aa_y"] <= 64:
+        from conftest import focal_for
+        if not coop_frames_equal(kw, scene, rot, cam, light, focal_for(abi.make_config(**kw)), ref):
+            print("MISMATCH seed %d: cooperative frames differ; n=%d kw=%s" % (seed, len(scene), kw), flush=True)
             return False
     return True
 
@@ -151,6 +170,9 @@ def one_case_wide(seed, stats=None):
             print("MISMATCH wide seed %d flags %d: %d pixels, first %s; %s kw=%s"
                   % (seed, fl, len(bad), bad[:1].tolist(), info, {q: kw[q] for q in kw if q != "spheres"}), flush=True)
             return False
+    if len(scene) > 64 and not coop_frames_equal(kw, scene, rot, cam, light, focal, ref):
+        print("MISMATCH wide seed %d: cooperative frames differ; %s" % (seed, info), flush=True)
+        return False
     return True
 
 

@@ -456,6 +456,7 @@ static void fill_params(const rt_ctx* c, const float rot[12], const float cam[3]
   }
   P->verts = c->d_verts; P->normals = c->d_normals; P->colors = c->d_colors;
   P->records = c->d_records;
+  P->mask_debug = c->tune.mask_debug;
   P->job_counter = c->d_jobctr + kJobHeadStride;      // [HeavyState 0 | queue heads | HeavyState 1], one line each
   {   // wave kernel: a job is a run of job_tasks 64-ray tasks (job_tasks * 64/aa pixels) of one row
     const int aa = g.aa_x * g.aa_y;
@@ -481,7 +482,6 @@ static void fill_params(const rt_ctx* c, const float rot[12], const float cam[3]
   if (c->d_screen_masks) {
     P->screen_masks = c->d_screen_masks; P->world_masks = c->d_world_masks; P->world_occ = c->d_world_occ;
     P->nwords = c->nwords; P->scx = c->scx; P->scy = c->scy; P->grid_g = kWorldGrid;
-    P->mask_debug = c->tune.mask_debug;
     // World grid: a cube over the scene box, grown so that every shadow-ray start point X + 1e-4 (light - X)
     // of a surface point X in the box (kernels.cl:324) stays inside, rounding included; X itself is computed
     // from the camera (X = cam + t dir, or v0 + u e1 + v e2), so its rounding scales with the camera's and the

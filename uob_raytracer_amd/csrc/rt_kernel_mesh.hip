@@ -999,7 +999,8 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
 // Next frame's job order from this frame's costs: expensive blocks first (64 linear cost classes; inside a class the
 // order is whatever the atomics make it — no pixel depends on it); a block that cost more than 8x the mean (and more than
 // a quarter of the dearest) is entered as four cooperative sub-block jobs.  One workgroup.
-__global__ __launch_bounds__(1024) void rt_mesh_order(const unsigned int* cost, unsigned int* order, unsigned int* queue_len, int n_jobs) {
+__global__ __launch_bounds__(1024) void rt_mesh_order(const unsigned int* cost, unsigned int* order, unsigned int* queue_len, int n_jobs,
+                                                      int coop_all) {
   __shared__ unsigned int smax, hist[64], base[64];
   __shared__ unsigned long long ssum;
   const int tid = threadIdx.x;
@@ -1013,8 +1014,9 @@ __global__ __launch_bounds__(1024) void rt_mesh_order(const unsigned int* cost, 
   atomicAdd(&ssum, sum);
   __syncthreads();
   const unsigned long long scale = (unsigned long long)smax + 1ull;
-  const unsigned long long heavy = 8ull * (ssum / (unsigned long long)(n_jobs > 0 ? n_jobs : 1)) > (unsigned long long)smax / 4ull
-                                       ? 8ull * (ssum / (unsigned long long)(n_jobs > 0 ? n_jobs : 1)) : (unsigned long long)smax / 4ull;
+  const unsigned long long mean8 = 8ull * (ssum / (unsigned long long)(n_jobs > 0 ? n_jobs : 1));
+  // coop_all (UOB_RT_MESH_COOP=1, tests): every block comes back cooperative
+  const unsigned long long heavy = coop_all ? 0ull : (mean8 > (unsigned long long)smax / 4ull ? mean8 : (unsigned long long)smax / 4ull);
   for (int i = tid; i < n_jobs; i += 1024)
     atomicAdd(&hist[63 - (int)((unsigned long long)cost[i] * 64ull / scale)], (unsigned long long)cost[i] > heavy ? 4u : 1u);
   __syncthreads();
@@ -1067,7 +1069,7 @@ void launch_mesh(const FrameParams& P, bool count, bool prof, hipStream_t stream
   else if (count) hipLaunchKernelGGL((rt_draw_mesh<true>), grid, block, lds_bytes, stream, P);
   else hipLaunchKernelGGL((rt_draw_mesh<false>), grid, block, lds_bytes, stream, P);
   if (!count && P.mesh_cost != nullptr && P.mesh_order_out != nullptr)
-    hipLaunchKernelGGL(rt_mesh_order, dim3(1), dim3(1024), 0, stream, P.mesh_cost, P.mesh_order_out, P.mesh_queue_len, n_jobs);
+    hipLaunchKernelGGL(rt_mesh_order, dim3(1), dim3(1024), 0, stream, P.mesh_cost, P.mesh_order_out, P.mesh_queue_len, n_jobs, (P.mask_debug & 8) ? 1 : 0);
 }
 
 int mesh_blocks_per_cu() { return RT_MESH_MIN_BLOCKS; }
