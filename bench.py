@@ -133,11 +133,15 @@ def main():
         frame = frame_pad[:H]
 
     # N > 1 over RCCL: the render of frame k+1 runs on its own stream into the other of two stripe buffers while
-    # the bands of frame k are gathered and de-interleaved on the current stream (events order the hand-overs)
+    # the bands of frame k are gathered and de-interleaved on the current stream (events order the hand-overs).
+    # Consecutive frames come from TWO contexts on two streams: the next frame's workgroups take the slots the draining
+    # one frees (a context runs its own frames one at a time).  Measured on one GPU with one rank's bands
+    # (tools/band_pipeline.py): 2048 rows 1.97 -> 1.72 ms per frame, 1024 rows 1.04 -> 0.90, 512 rows 0.63 -> 0.63.
     pipelined = collective and args.backend == "nccl"
     if pipelined:
-        render_stream = torch.cuda.Stream(device=dev)
-        stripes = [stripe, torch.empty_like(stripe)]
+        render_streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+        tracers = [tracer, rt.RayTracer(cfg, scene)]
+        stripes = [stripe, torch.zeros_like(stripe)]
         rendered = [torch.cuda.Event(), torch.cuda.Event()]     # stripe i holds a finished frame
         consumed = [None, None]                                 # the gather that read stripe i has finished
     state = {"k": 0}
@@ -147,11 +151,12 @@ def main():
             i = state["k"] % 2
             state["k"] += 1
             cur = torch.cuda.current_stream()
+            render_stream = render_streams[i]
             if consumed[i] is not None:
                 render_stream.wait_event(consumed[i])
             if ev:
                 ev[0].record(render_stream)
-            tracer.render_device(rot, cam, light, focal, stripes[i].data_ptr(), None, render_stream.cuda_stream)
+            tracers[i].render_device(rot, cam, light, focal, stripes[i].data_ptr(), None, render_stream.cuda_stream)
             if ev:
                 ev[1].record(render_stream)
             rendered[i].record(render_stream)
@@ -256,7 +261,8 @@ def main():
     except (OSError, ValueError):
         pass
     traffic = pmc["hbm_bytes_per_launch"] / world if pmc else None
-    kernel_s = kernel_ms * 1e-3
+    # with two contexts in flight (N > 1) consecutive kernels overlap: a launch's share of the device is the frame period
+    kernel_s = (min(kernel_ms, ms_per_step) if pipelined else kernel_ms) * 1e-3
     slot_flop = 64 * 2 * VALU_ISSUE_CYCLES / 2          # flop an FMA delivers in one issue slot of a wave64 instruction
     if pmc:
         valu = pmc["valu_instructions_per_launch"] / world
