@@ -118,7 +118,9 @@ int rt_render(rt_ctx* ctx, const float rot[12], const float cam[3], const float 
 
 /* Same frame, but the ARGB (and optional float4) output stays in device memory the caller owns
  * (e.g. a torch tensor handed to an RCCL gather).  Enqueued on `hip_stream` (a hipStream_t, may be
- * NULL for the default stream); returns without synchronising.                                       */
+ * NULL for the default stream); returns without synchronising.  With several devices in the context
+ * (rt_config.devices) the buffers must live on devices[0] and hip_stream must be a stream of that device: the other
+ * devices' bands arrive by peer copy, ordered after the caller's earlier work on the stream and before its later work. */
 int rt_render_device(rt_ctx* ctx, const float rot[12], const float cam[3], const float light[3],
                      float focal, void* d_out_argb, void* d_out_rgb_f32, void* hip_stream);
 
