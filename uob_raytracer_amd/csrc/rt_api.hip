@@ -46,7 +46,7 @@ bool generic_needs_records(int n);
 void launch_stage_records(const FrameParams& P, hipStream_t stream);
 void launch_trace_rays(const FrameParams& P, int what, const float* d_rays, const float* d_r2, long nray, int* d_tri,
                        float* d_out10, hipStream_t stream);
-void launch_mesh(const FrameParams& P, bool count, bool prof, hipStream_t stream);
+void launch_mesh(const FrameParams& P, bool count, bool prof, hipStream_t stream, hipStream_t aux, hipEvent_t ev_fork, hipEvent_t ev_join);
 bool mesh_kernel_supports(const FrameParams& P);
 int mesh_tiles(int n);
 int mesh_occ_words(int grid);
@@ -111,6 +111,8 @@ struct rt_ctx {
   int nwords = 0, scx = 0, scy = 0;
   float box_lo[3] = {0, 0, 0}, box_hi[3] = {0, 0, 0};
   hipStream_t stream = nullptr;
+  hipStream_t aux_stream = nullptr;             // mesh kernel: the primary-ray masks are built beside the shadow-ray masks
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
   hipStream_t last_stream = nullptr;
@@ -370,6 +372,11 @@ int rt_init(const rt_config* cfg, const float* vertices4, const float* normals4,
         hipMalloc(&c->d_world_occ, (size_t)mesh_occ_words(kWorldGrid) * sizeof(unsigned int)) != hipSuccess) {
       set_error("hipMalloc failed: %s", hipGetErrorString(hipGetLastError())); return fail(RT_E_NOMEM);
     }
+    if (hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+      set_error("stream/event creation failed"); return fail(RT_E_DEVICE);
+    }
     // every surface point lies on a triangle or a sphere: their bounding box (the world grid spans it)
     for (int k = 0; k < 3; ++k) { c->box_lo[k] = 3.0e38f; c->box_hi[k] = -3.0e38f; }
     for (size_t v = 0; v < (size_t)n * 3; ++v)
@@ -558,7 +565,7 @@ static int launch_frame(rt_ctx* c, const float rot[12], const float cam[3], cons
       c->mesh_order_valid = true;
     }
     launch_stage_records(P, stream);        // per frame: the records hold camera-dependent terms
-    launch_mesh(P, false, false, stream);
+    launch_mesh(P, false, false, stream, c->aux_stream, c->ev_fork, c->ev_join);
   } else {
     launch_generic(P, false, stream);
   }
@@ -731,7 +738,7 @@ int rt_count_executed(rt_ctx* c, const float rot[12], const float cam[3], const 
   HIP_TRY(hipSetDevice(c->device));
   if (c->timed) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev1, 0));
   HIP_TRY(hipMemsetAsync(c->d_counters, 0, sizeof(rt_work), c->stream));
-  if (mesh) { use_tiled_scene(c, &P); launch_stage_records(P, c->stream); launch_mesh(P, true, c->tune.phase_profile, c->stream); }
+  if (mesh) { use_tiled_scene(c, &P); launch_stage_records(P, c->stream); launch_mesh(P, true, c->tune.phase_profile, c->stream, nullptr, nullptr, nullptr); }
   else if (c->tune.phase_profile) launch_wave_prof(P, c->stream);   // diagnostic: s_memtime per phase
   else launch_wave(P, !(c->cfg.flags & RT_FLAG_NO_CULL), true, c->stream);
   HIP_TRY(hipGetLastError());
@@ -830,6 +837,9 @@ void rt_destroy(rt_ctx* c) {
   if (c->stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); }
   if (c->ev0) hipEventDestroy(c->ev0);
   if (c->ev1) hipEventDestroy(c->ev1);
+  if (c->aux_stream) { hipStreamSynchronize(c->aux_stream); hipStreamDestroy(c->aux_stream); }
+  if (c->ev_fork) hipEventDestroy(c->ev_fork);
+  if (c->ev_join) hipEventDestroy(c->ev_join);
   if (c->ev_go) hipEventDestroy(c->ev_go);
   if (c->ev_done) hipEventDestroy(c->ev_done);
   hipFree(c->d_verts); hipFree(c->d_normals); hipFree(c->d_colors);

@@ -1047,16 +1047,22 @@ int mesh_occ_words(int grid) { return occ_words(grid); }
 int mesh_screen_cells(int pixels) { return (pixels + kScreenCell - 1) / kScreenCell; }
 
 // P.records must hold this frame's records (launch_stage_records) before the masks are built.
-void launch_mesh(const FrameParams& P, bool count, bool prof, hipStream_t stream) {
+// `aux`, `ev_fork`, `ev_join` (all nullable): a second stream and two events of the context, so that the primary-ray tile
+// masks are built beside the world-cell occupancy + shadow-ray masks instead of in front of them.
+void launch_mesh(const FrameParams& P, bool count, bool prof, hipStream_t stream, hipStream_t aux, hipEvent_t ev_fork, hipEvent_t ev_join) {
   const dim3 block(64 * kMeshWaves);
   const int ntiles = mesh_tiles(P.n), nwords = (ntiles + 63) / 64;
   if (P.screen_masks != nullptr) {
     hipMemsetAsync(P.screen_masks, 0, (size_t)P.scx * P.scy * nwords * 8, stream);
     hipMemsetAsync(P.world_masks, 0, (size_t)P.grid_g * P.grid_g * P.grid_g * nwords * 8, stream);
     hipMemsetAsync(P.world_occ, 0, (size_t)occ_words(P.grid_g) * sizeof(unsigned int), stream);
+    const bool fork = aux != nullptr && ev_fork != nullptr && ev_join != nullptr &&
+                      hipEventRecord(ev_fork, stream) == hipSuccess && hipStreamWaitEvent(aux, ev_fork, 0) == hipSuccess;
+    hipLaunchKernelGGL(rt_bin_primary, dim3((ntiles + kMeshWaves - 1) / kMeshWaves, P.scy), block, 0, fork ? aux : stream, P);
+    if (fork) hipEventRecord(ev_join, aux);
     hipLaunchKernelGGL(rt_bin_occupancy, dim3((P.n + P.nsph + 255) / 256), dim3(256), 0, stream, P);
-    hipLaunchKernelGGL(rt_bin_primary, dim3((ntiles + kMeshWaves - 1) / kMeshWaves, P.scy), block, 0, stream, P);
     hipLaunchKernelGGL(rt_bin_shadow, dim3((ntiles + kMeshWaves - 1) / kMeshWaves, P.grid_g / 4, P.grid_g / 4), block, 0, stream, P);
+    if (fork) hipStreamWaitEvent(stream, ev_join, 0);
   }
   const int n_jobs = ((P.W + 15) / 16) * ((P.owned_rows + 15) / 16);
   const int resident = P.mesh_blocks > 0 ? P.mesh_blocks : 256 * RT_MESH_MIN_BLOCKS;
