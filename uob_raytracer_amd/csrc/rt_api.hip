@@ -103,6 +103,7 @@ struct rt_ctx {
   // triangles first, then Morton order of the centroids), the original index of each triangle, and the tiles' boxes
   float4 *d_verts_m = nullptr, *d_normals_m = nullptr, *d_colors_m = nullptr, *d_tile_box = nullptr;
   int* d_orig = nullptr;
+  DevSphere* d_spheres = nullptr;  // the sphere table in device memory (the wave-mapped kernels stage it into LDS)
   unsigned int *d_mesh_cost = nullptr, *d_mesh_order = nullptr;   // per 16x16-pixel block: last frame's cost, this frame's order
   bool mesh_order_valid = false;
   // mesh kernel: per-frame candidate-tile masks (rt_kernel_mesh.hip) and the scene's bounding box for its world grid
@@ -417,6 +418,18 @@ int rt_init(const rt_config* cfg, const float* vertices4, const float* normals4,
       set_error("scene upload failed: %s", hipGetErrorString(hipGetLastError())); return fail(RT_E_DEVICE);
     }
   }
+  {
+    DevSphere tab[RT_MAX_SPHERES];
+    memset(tab, 0, sizeof tab);
+    for (int i = 0; i < cfg->num_spheres; ++i) {
+      tab[i].cx = cfg->spheres[i].center[0]; tab[i].cy = cfg->spheres[i].center[1]; tab[i].cz = cfg->spheres[i].center[2];
+      tab[i].r2 = cfg->spheres[i].radius_sq;
+      memcpy(tab[i].col, cfg->spheres[i].color, 16);
+    }
+    if (hipMalloc(&c->d_spheres, sizeof tab) != hipSuccess || hipMemcpy(c->d_spheres, tab, sizeof tab, hipMemcpyHostToDevice) != hipSuccess) {
+      set_error("sphere table upload failed: %s", hipGetErrorString(hipGetLastError())); return fail(RT_E_DEVICE);
+    }
+  }
   c->n_shadow = 0;
   for (int i = 0; i < n; ++i) c->n_shadow += (colors4[4 * i + 3] != -1.0f);
   if (n > 64 && !(cfg->flags & RT_FLAG_GENERIC_KERNEL)) {
@@ -450,6 +463,16 @@ static void fill_params(const rt_ctx* c, const float rot[12], const float cam[3]
   P->band_rows = g.band_rows; P->band_index = g.band_index; P->band_count = g.band_count;
   P->owned_rows = c->owned_rows;
   P->sy = (float)g.aa_x / (float)g.aa_y;
+  {   // frame invariants of the reference's arithmetic (rt_device.h), same FP32 operations as the kernels would perform
+    P->half_wx = ((float)g.width * (float)g.aa_x) / 2.0f;
+    P->half_hy = ((float)g.height * (float)g.aa_y) / 2.0f;
+    P->w_f = (float)g.width;
+    P->focal0 = focal + 0.0f;
+    P->rzf[0] = rot[2] * P->focal0; P->rzf[1] = rot[6] * P->focal0; P->rzf[2] = rot[10] * P->focal0;
+    P->hbox = g.light_spread / 2.f;
+    P->light_inf = fmaxf(fmaxf(fabsf(light[0]), fabsf(light[1])), fabsf(light[2]));
+    P->band_rows_magic = g.band_rows > 1 ? (uint32_t)((0x100000000ull + (uint64_t)g.band_rows - 1) / (uint64_t)g.band_rows) : 0u;
+  }
   {
     const int aa = g.aa_x * g.aa_y;
     P->inv_S = (g.shadow_samples & (g.shadow_samples - 1)) == 0 ? 1.0f / (float)g.shadow_samples : 0.0f;
@@ -462,6 +485,7 @@ static void fill_params(const rt_ctx* c, const float rot[12], const float cam[3]
     memcpy(P->sph[i].col, g.spheres[i].color, 16);
   }
   P->verts = c->d_verts; P->normals = c->d_normals; P->colors = c->d_colors;
+  P->sph_dev = c->d_spheres;
   P->records = c->d_records;
   P->mask_debug = c->tune.mask_debug;
   P->job_counter = c->d_jobctr + kJobHeadStride;      // [HeavyState 0 | queue heads | HeavyState 1], one line each
@@ -485,6 +509,11 @@ static void fill_params(const rt_ctx* c, const float rot[12], const float cam[3]
     const int job_pixels = jt * pt;
     P->nseg = (g.width + job_pixels - 1) / job_pixels;
     P->njobs = P->nseg * c->owned_rows;
+    P->nseg_magic = P->nseg > 1 ? (uint32_t)((0x100000000ull + (uint64_t)P->nseg - 1) / (uint64_t)P->nseg) : 0u;
+    P->job_hx = 0.5f * (float)(job_pixels * g.aa_x - 1);
+    P->job_hy = 0.5f * (float)(g.aa_y - 1) * P->sy;
+    for (int k = 0; k < 3; ++k)
+      P->job_eu[k] = 1.0001f * (fabsf(rot[4 * k]) * P->job_hx + fabsf(rot[4 * k + 1]) * P->job_hy);
   }
   if (c->d_screen_masks) {
     P->screen_masks = c->d_screen_masks; P->world_masks = c->d_world_masks; P->world_occ = c->d_world_occ;
@@ -846,7 +875,7 @@ void rt_destroy(rt_ctx* c) {
   hipFree(c->d_argb); hipFree(c->d_rgb); hipFree(c->d_counters); hipFree(c->d_records); hipFree(c->d_jobctr);
   hipFree(c->d_screen_masks); hipFree(c->d_world_masks); hipFree(c->d_world_occ);
   hipFree(c->d_heavy[0]); hipFree(c->d_heavy[1]); hipFree(c->d_heavy_flags);
-  hipFree(c->d_mesh_cost); hipFree(c->d_mesh_order);
+  hipFree(c->d_mesh_cost); hipFree(c->d_mesh_order); hipFree(c->d_spheres);
   hipFree(c->d_verts_m); hipFree(c->d_normals_m); hipFree(c->d_colors_m); hipFree(c->d_orig); hipFree(c->d_tile_box);
   delete c;
 }

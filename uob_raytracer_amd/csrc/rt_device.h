@@ -38,10 +38,25 @@ struct FrameParams {
   int32_t n;              // triangles
   int32_t band_rows, band_index, band_count, owned_rows;
   float sy;               // aa_x / aa_y: y sub-pixel pitch in x sub-pixel units (1 for square grids)
+  // Frame invariants of the reference's arithmetic, evaluated once on the host with the same FP32 operations (rt_api.hip
+  // is built with -ffp-contract=off too).  gfx950 has no scalar float ALU: inside the kernel the compiler computes such
+  // uniform values with VECTOR instructions, hoists them out of the job loop and keeps them in vector registers (17 of
+  // the wave kernel's 96, all spilled to scratch and re-loaded for every job); as kernel arguments they are scalar operands.
+  float half_wx, half_hy; // ((float)W * (float)aa_x) / 2.0f, ((float)H * (float)aa_y) / 2.0f   (kernels.cl:384)
+  float w_f;              // (float)W                                                           (kernels.cl:380)
+  float focal0;           // focal + 0.0f: z of the un-rotated ray direction
+  float rzf[3];           // rot[2] * focal0, rot[6] * focal0, rot[10] * focal0: the last product of each row of R.d
+  float hbox;             // light_spread / 2.f                                                 (kernels.cl:51)
+  float light_inf;        // max |light_k|
+  float job_hx, job_hy;   // wave kernel: half extent of a job's sub-pixel rectangle
+  float job_eu[3];        // wave kernel: 1.0001 * (|r_k.x| * job_hx + |r_k.y| * job_hy): half width of the job's direction box
+  uint32_t nseg_magic, band_rows_magic;   // ceil(2^32 / d) for q = n / d by one multiply-high (0: d == 1)
   float inv_S, inv_aa;    // 1/S, 1/(aa_x*aa_y) when that count is a power of two (x / 2^k == x * 2^-k bit for bit,
                           // one multiplication instead of an IEEE division), else 0
   int32_t n_shadow;       // triangles that can cast a shadow (glass removed), for the wave kernel
   DevSphere sph[RT_MAX_SPHERES];
+  const DevSphere* sph_dev;   // the same table in device memory: the wave-mapped kernels stage it into LDS (as kernel
+                              // arguments the spheres sit in 16-32 scalar registers for the whole kernel)
   const float4* verts;    // float4[3n]  (HBM, read once per workgroup while staging into LDS)
   const float4* normals;  // float4[n]
   const float4* colors;   // float4[n], w = material flag
@@ -85,9 +100,20 @@ struct FrameParams {
   float grid_lo[3], grid_cell, grid_inv;   // world grid: origin, cell edge, 1 / cell edge
 };
 
+// n / d for n < 2^16 * ... (rows, jobs) with the host's magic = ceil(2^32 / d): exact while n * (magic * d - 2^32) < 2^32,
+// which holds for every row index (< 2^15) and job index (< 2^20, d <= 2^11) of a frame; magic 0 stands for d == 1
+__device__ inline uint32_t div_magic(uint32_t n, uint32_t magic) { return magic ? __umulhi(n, magic) : n; }
+
 // Map a packed local row index to the global image row (band partition, include/uob_rt.h rt_config).
 __host__ __device__ inline int band_global_row(int lr, int band_rows, int band_index, int band_count) {
   return ((lr / band_rows) * band_count + band_index) * band_rows + (lr % band_rows);
+}
+// the same with the division done by the frame's magic number
+__device__ inline int band_global_row(const struct FrameParams& P, int lr);
+
+__device__ inline int band_global_row(const FrameParams& P, int lr) {
+  const int q = (int)div_magic((uint32_t)lr, P.band_rows_magic);
+  return (q * P.band_count + P.band_index) * P.band_rows + (lr - q * P.band_rows);
 }
 
 }  // namespace uobrt

@@ -19,6 +19,7 @@
 // A brute-force pass over 100 k triangles costs ~100 k tests per ray; here it costs one bound per
 // (64-ray task, triangle) plus the few real tests.  Mirror / glass bounce rays run in rounds, the workgroup's four
 // tasks together, every round streaming all tiles through LDS with the same lane = triangle bound in front.
+#define RT_SPHERES_IN_LDS
 #include "rt_wave_common.h"
 
 namespace uobrt {
@@ -388,6 +389,7 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
   // the context's PREVIOUS frame first (P.mesh_order, built by rt_mesh_order from the costs each job records; the
   // first frame goes from the middle rows outwards).  No pixel depends on the order.
   __shared__ int s_job;
+  stage_spheres(P, tid);                               // (the job loop's first barrier publishes them)
   const int wgx_n = (P.W + 15) / 16, wgy_n = (P.owned_rows + 15) / 16, n_jobs = wgx_n * wgy_n;
   const int n_queue = P.mesh_order != nullptr ? (int)P.mesh_queue_len[0] : n_jobs;
   const int wg_mid = (wgy_n + 1) >> 1;

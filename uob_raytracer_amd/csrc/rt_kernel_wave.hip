@@ -33,6 +33,7 @@
 //
 // Arithmetic is the reference's, operation for operation (rt_math.h): results are bit-identical to the
 // generic kernel and to the CPU oracle.
+#define RT_SPHERES_IN_LDS
 #include "rt_wave_common.h"
 
 #ifndef RT_OPT_SPHJOB
@@ -269,6 +270,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
 
   // ---- stage the triangle list once per workgroup ---------------------------------------------------
   stage_triangles(P, lds, tid, 64 * kWavesPerBlock, st);
+  stage_spheres(P, tid);
   int* sidx = reinterpret_cast<int*>(lds + kLdsRecords * st);         // shadow-casting triangles, in order
   if (wave == 0) {                                                    // n <= 64 on this path (supports())
     const bool casts = (lane < n) && (P.colors[lane < n ? lane : 0].w != -1.0f);   // glass casts no shadow, :247
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
   const int PT = 64 / aa;                                             // pixels per task (lanes >= PT * aa idle)
   const int GP = PT < kRngPixels ? PT : kRngPixels;                   // pixels per RNG group
   const f3 light = mk(P.light[0], P.light[1], P.light[2]);
-  const float hbox = P.spread / 2.f;                                  // |crush()| <= range/2, :51
+  const float hbox = P.hbox;                                          // |crush()| <= range/2, :51
   const unsigned long long tri_lanes = ns == 64 ? ~0ull : ((1ull << ns) - 1ull);
   const int NS = P.S;                                                 // shadow samples = sample lanes, <= 64
   const int n_pass = MULTI ? (NS + 63) >> 6 : 1;                      // passes of 64 sample lanes
@@ -378,12 +380,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
   // Rows are handed out from the middle of the rank's rows outwards: segments differ 10x in cost, and the kernel
   // ends when the last job does, so the last jobs should be cheap ones — the top and bottom rows of a view
   // usually are (background, plain walls).
-  const int jrow = job / P.nseg;
+  const int jrow = (int)div_magic((uint32_t)job, P.nseg_magic);
   const int mid = (P.owned_rows + 1) >> 1;
   const int lr = (jrow & 1) ? mid + (jrow >> 1) : mid - 1 - (jrow >> 1);
   const int JP = jt * PT;                          // pixels of this hand-out
   const int x0 = (job - jrow * P.nseg) * JP;
-  const int y = band_global_row(lr, P.band_rows, P.band_index, P.band_count);
+  const int y = band_global_row(P, lr);
   f3 outc = mk(0.f, 0.f, 0.f);
   // Triangles a primary ray of this job may hit, bounded once for the job's 64 x 1 pixels (all AA samples): the
   // rays leave the camera through a sub-pixel rectangle, see primary_clear.  (Per task the rectangle is 8x
@@ -392,15 +394,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
   bool sph_job = P.nsph > 0;
   if (CULL) {
     const int lnJ = opaque(lane);
-    const float Xlo = (float)(x0 * P.aa_x) - ((float)P.W * (float)P.aa_x) / 2.0f;
-    const float Ylo = ((float)(y * P.aa_y) - ((float)P.H * (float)P.aa_y) / 2.0f) * P.sy;
-    const float hx = 0.5f * (float)(JP * P.aa_x - 1), hy = 0.5f * (float)(P.aa_y - 1) * P.sy;
-    const f3 wc = mk(Xlo + hx, Ylo + hy, P.focal);
-    const f3 r0 = mk(P.rot[0], P.rot[1], P.rot[2]), r1 = mk(P.rot[4], P.rot[5], P.rot[6]),
-             r2 = mk(P.rot[8], P.rot[9], P.rot[10]);
-    const f3 duc = mk(dot3(r0, wc), dot3(r1, wc), dot3(r2, wc));
-    const f3 eu = mk(1.0001f * (fabsf(r0.x) * hx + fabsf(r0.y) * hy), 1.0001f * (fabsf(r1.x) * hx + fabsf(r1.y) * hy),
-                     1.0001f * (fabsf(r2.x) * hx + fabsf(r2.y) * hy));
+    const float Xlo = (float)(x0 * P.aa_x) - P.half_wx;
+    const float Ylo = ((float)(y * P.aa_y) - P.half_hy) * P.sy;
+    // a hand-out narrower than a job (none at present) would only make the box generous
+    const f3 wc = mk(Xlo + P.job_hx, Ylo + P.job_hy, P.focal);
+    const f3 duc = mk(P.rot[0] * wc.x + P.rot[1] * wc.y + P.rzf[0], P.rot[4] * wc.x + P.rot[5] * wc.y + P.rzf[1],
+                      P.rot[8] * wc.x + P.rot[9] * wc.y + P.rzf[2]);
+    const f3 eu = mk(P.job_eu[0], P.job_eu[1], P.job_eu[2]);
     const float dumax = fmaxf(fmaxf(fabsf(duc.x) + eu.x, fabsf(duc.y) + eu.y), fabsf(duc.z) + eu.z);
     const int ti = lnJ < n ? lnJ : 0;
     const float4 c4 = S.c[ti];
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
         const float dlen0 = rl(dlen, jr);
         const float dlen_max = (dlen0 + 1.7321f * ed) * 1.000001f;
         const float dlen_min = fmaxf(dlen0 - 1.7321f * ed, 0.0f) * 0.999999f;
-        const float es = 1.0002f * ed + 2e-6f * (norm_inf(light) + dlen_max);
+        const float es = 1.0002f * ed + 2e-6f * (P.light_inf + dlen_max);
         const bool all_sane = ballot(lit && !sane) == 0ull;
         if (all_sane && es < 1e30f && ed < 1e30f) {                    // finite, non-degenerate
           const float hh_task = 1.002f * hbox + 2e-6f * (dlen_max + hbox);

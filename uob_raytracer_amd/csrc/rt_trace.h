@@ -50,6 +50,19 @@ __device__ __forceinline__ void stage_triangles(const FrameParams& P, float4* ld
   }
 }
 
+// The sphere table: kernel argument (scalar registers) by default; a translation unit that defines RT_SPHERES_IN_LDS
+// reads it from LDS instead, where its kernels stage it once per workgroup (stage_spheres) — the culls leave few rays
+// that look at a sphere, and the scalar registers are the scarcer resource of the wave-mapped kernels.
+#ifdef RT_SPHERES_IN_LDS
+__shared__ DevSphere g_sph[RT_MAX_SPHERES];
+#define RT_SPH(P, i) g_sph[i]
+__device__ __forceinline__ void stage_spheres(const FrameParams& P, int tid) {
+  if (tid < P.nsph * 8) reinterpret_cast<float*>(g_sph)[tid] = reinterpret_cast<const float*>(P.sph_dev)[tid];
+}
+#else
+#define RT_SPH(P, i) P.sph[i]
+#endif
+
 struct Ray {           // kernels.cl:21-29
   f3 start, dir, P, N;
   float4 col;
@@ -70,7 +83,7 @@ enum { W_PRIMARY, W_BOUNCE, W_SHADOW, W_CTRI, W_CSPH, W_STRI, W_SSPH, W_LIT };
 template <bool COUNT>
 __device__ __forceinline__ void closest_spheres(const FrameParams& P, Ray& ray, float& current_t, Work& wk) {
   for (int i = 0; i < P.nsph; ++i) {
-    const DevSphere& sp = P.sph[i];
+    const DevSphere& sp = RT_SPH(P, i);
     const f3 ctr = mk(sp.cx, sp.cy, sp.cz);
     const f3 L = ray.start - ctr;
     const float a = dot3(ray.dir, ray.dir);
@@ -210,7 +223,7 @@ __device__ inline void closest_hit_masked(const LdsScene& S, const FrameParams& 
 template <bool COUNT>
 __device__ __forceinline__ bool shadow_spheres(const FrameParams& P, f3 start, f3 dir, float radius_sq, Work& wk) {
   for (int i = 0; i < P.nsph; ++i) {
-    const DevSphere& sp = P.sph[i];
+    const DevSphere& sp = RT_SPH(P, i);
     if (sp.col[3] == -1.0f) continue;
     const f3 L = start - mk(sp.cx, sp.cy, sp.cz);
     const float a = dot3(dir, dir);
@@ -305,15 +318,15 @@ __device__ bool bounce_to_diffuse(const LdsScene& S, const FrameParams& P, Ray& 
 // Primary ray through AA sample (dx,dy) of pixel (x,y): kernels.cl:384-407.  Units are AA sub-pixels
 // along x; sy = aa_x/aa_y rescales the y pitch for non-square grids (1 for the reference's square ones).
 __device__ __forceinline__ Ray primary_ray(const FrameParams& P, int x, int y, int dx, int dy) {
-  const float Wf = (float)P.W, Hf = (float)P.H;
-  const float bx = (float)(x * P.aa_x) - (Wf * (float)P.aa_x) / 2.0f;
-  const float by = (float)(y * P.aa_y) - (Hf * (float)P.aa_y) / 2.0f;
-  const f3 r0 = mk(P.rot[0], P.rot[1], P.rot[2]), r1 = mk(P.rot[4], P.rot[5], P.rot[6]),
-           r2 = mk(P.rot[8], P.rot[9], P.rot[10]);
+  // (Wf*rx)/2, (Hf*ry)/2, focal + 0 and r_k.z * d.z are frame invariants, evaluated on the host with the same operations
+  const float bx = (float)(x * P.aa_x) - P.half_wx;
+  const float by = (float)(y * P.aa_y) - P.half_hy;
   Ray ray;
   ray.start = mk(P.cam[0], P.cam[1], P.cam[2]);
-  const f3 d = mk(bx + (float)dx, (by + (float)dy) * P.sy, P.focal + 0.0f);
-  ray.dir = normalize3(mk(dot3(r0, d), dot3(r1, d), dot3(r2, d)));
+  const float dxs = bx + (float)dx, dys = (by + (float)dy) * P.sy;
+  // dot(r_k, d) = r_k.x*d.x + r_k.y*d.y + r_k.z*d.z, left to right
+  ray.dir = normalize3(mk(P.rot[0] * dxs + P.rot[1] * dys + P.rzf[0], P.rot[4] * dxs + P.rot[5] * dys + P.rzf[1],
+                          P.rot[8] * dxs + P.rot[9] * dys + P.rzf[2]));
   ray.tri = -1;
   ray.medium = RT_AIR;
   ray.col = make_float4(0.f, 0.f, 0.f, 1.0f);
@@ -332,7 +345,7 @@ __device__ __forceinline__ uint32_t pack_argb(f3 c) {
 
 // kernels.cl:380 — the pixel id is formed in FP32
 __device__ __forceinline__ int pixel_global_id(const FrameParams& P, int x, int y) {
-  return (int)((float)y * (float)P.W + (float)x);
+  return (int)((float)y * P.w_f + (float)x);
 }
 
 }  // namespace uobrt

@@ -324,7 +324,7 @@ __device__ __forceinline__ bool sphere_bundle_maybe(const FrameParams& P, f3 o, 
   bool maybe = false;
   const float eo2 = 1.7321f * 1.001f * eo;
   for (int i = 0; i < P.nsph; ++i) {
-    const DevSphere& sp = P.sph[i];
+    const DevSphere& sp = RT_SPH(P, i);
     if (casters_only && sp.col[3] == -1.0f) continue;
     const f3 Lv = o - mk(sp.cx, sp.cy, sp.cz);
     const f3 cr = mk(Lv.y * dir.z - Lv.z * dir.y, Lv.z * dir.x - Lv.x * dir.z, Lv.x * dir.y - Lv.y * dir.x);
@@ -349,7 +349,7 @@ __device__ __forceinline__ SphereBound spheres_point(const FrameParams& P, f3 st
   r.maybe = false; r.all_blocked = false;
   const float jm = 1.7321f * hh;
   for (int i = 0; i < P.nsph; ++i) {
-    const DevSphere& sp = P.sph[i];
+    const DevSphere& sp = RT_SPH(P, i);
     if (sp.col[3] == -1.0f) continue;                               // glass casts no shadow, :279
     const f3 Lv = start - mk(sp.cx, sp.cy, sp.cz);
     const f3 cr = mk(Lv.y * dir.z - Lv.z * dir.y, Lv.z * dir.x - Lv.x * dir.z, Lv.x * dir.y - Lv.y * dir.x);
