@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void rt_draw_generic(const FrameParams P) {
 
   if (x < P.W && lr < P.owned_rows) {
     const LdsScene S = lds_scene(lds, P.n);
-    const int y = band_global_row(lr, P.band_rows, P.band_index, P.band_count);
+    const int y = band_global_row(P, lr);
     const int global_id = pixel_global_id(P, x, y);
     f3 total = mk(0.f, 0.f, 0.f);
     for (int dy = 0; dy < P.aa_y; ++dy) {

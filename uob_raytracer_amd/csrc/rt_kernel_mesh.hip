@@ -140,7 +140,7 @@ __device__ __forceinline__ void generate_streams(const FrameParams& P, const Mes
     const int pp = lane / 3, comp = lane % 3;
     const int qq = B.q(k, first_p + pp) < 64 ? B.q(k, first_p + pp) : 63;      // a pixel past the block is never lit
     const int px = B.x0 + zorder_x(qq);
-    const int py = band_global_row(B.lr0 + zorder_y(qq), P.band_rows, P.band_index, P.band_count);
+    const int py = band_global_row(P, B.lr0 + zorder_y(qq));
     const int gid = pixel_global_id(P, px, py);
     const uint32_t seed = comp == 0 ? (uint32_t)gid : (uint32_t)((float)gid * (comp == 1 ? 91.0f : 19.0f));
     uint32_t s = xorshift(seed);
@@ -180,13 +180,13 @@ __global__ __launch_bounds__(64 * kMeshWaves) void rt_bin_primary(const FramePar
   const int cy = blockIdx.y;
   const int ylo = cy * kScreenCell, yhi = (ylo + kScreenCell - 1) < P.H ? (ylo + kScreenCell - 1) : (P.H - 1);
   // sub-pixel rectangle of the cell, in the units of primary_ray() (rt_trace.h)
-  const float Ylo = ((float)(ylo * P.aa_y) - ((float)P.H * (float)P.aa_y) / 2.0f) * P.sy;
-  const float Yhi = ((float)(yhi * P.aa_y + P.aa_y - 1) - ((float)P.H * (float)P.aa_y) / 2.0f) * P.sy;
+  const float Ylo = ((float)(ylo * P.aa_y) - P.half_hy) * P.sy;
+  const float Yhi = ((float)(yhi * P.aa_y + P.aa_y - 1) - P.half_hy) * P.sy;
   const float hy = 0.5f * (Yhi - Ylo);
   for (int cx = 0; cx < P.scx; ++cx) {
     const int xlo = cx * kScreenCell, xhi = (xlo + kScreenCell - 1) < P.W ? (xlo + kScreenCell - 1) : (P.W - 1);
-    const float Xlo = (float)(xlo * P.aa_x) - ((float)P.W * (float)P.aa_x) / 2.0f;
-    const float Xhi = (float)(xhi * P.aa_x + P.aa_x - 1) - ((float)P.W * (float)P.aa_x) / 2.0f;
+    const float Xlo = (float)(xlo * P.aa_x) - P.half_wx;
+    const float Xhi = (float)(xhi * P.aa_x + P.aa_x - 1) - P.half_wx;
     const float hx = 0.5f * (Xhi - Xlo);
     const f3 wc = mk(Xlo + hx, Ylo + hy, P.focal);
     const f3 duc = mk(dot3(r0, wc), dot3(r1, wc), dot3(r2, wc));
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void rt_bin_occupancy(const FrameParams P) {
   }
   bool valid = i < P.n + P.nsph;
   const float amax = fmaxf(fmaxf(fmaxf(fabsf(lo.x), fabsf(hi.x)), fmaxf(fabsf(lo.y), fabsf(hi.y))), fmaxf(fabsf(lo.z), fabsf(hi.z)));
-  const float lmax = max_abs3(P.light[0], P.light[1], P.light[2]);
+  const float lmax = P.light_inf;
   // A point on a triangle is v0 + u e1 + v e2 with u, v in [0,1]: inside the triangle's box whatever the ray was.  A hit
   // point on a SPHERE is X = start + x dir (kernels.cl:225) with x from the quadratic's discriminant b*b - 4*a*c, which
   // the reference rounds by up to ~16 eps |d|^2 |L|^2 (L = start - centre): x is off by up to 4 sqrt(eps) |L| / |d| =
@@ -303,8 +303,8 @@ __global__ __launch_bounds__(64 * kMeshWaves) void rt_bin_shadow(const FramePara
   T1.c = xyz(P.records[(size_t)3 * n + g]);
   T1.c1 = norm1(T1.c); T1.e1_1 = norm1(T1.e1); T1.e2_1 = norm1(T1.e2);
   const f3 light = mk(P.light[0], P.light[1], P.light[2]);
-  const float linf = norm_inf(light);
-  const float hbox = P.spread / 2.f;
+  const float linf = P.light_inf;
+  const float hbox = P.hbox;
   const float half = 0.5f * P.grid_cell;
   const int G = P.grid_g;
   const float tv0inf = fmaxf(fmaxf(fabsf(T1.v0.x), fabsf(T1.v0.y)), fabsf(T1.v0.z));
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
       for (int r = 0; r < 16; ++r) {                      // the workgroup's 16 packed rows: global y may jump at a band edge
         const int lrr = wg_row * 16 + r;
         if (lrr >= P.owned_rows) break;
-        const int cy = band_global_row(lrr, P.band_rows, P.band_index, P.band_count) >> kScreenCellLog;
+        const int cy = band_global_row(P, lrr) >> kScreenCellLog;
         if (cy != last) m |= P.screen_masks[((size_t)cy * P.scx + cx) * nwords + w];
         last = cy;
       }
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
   const int GP = PT < kRngPixels ? PT : kRngPixels;
   const int GL = GP * aa;
   const f3 light = mk(P.light[0], P.light[1], P.light[2]);
-  const float hbox = P.spread / 2.f;
+  const float hbox = P.hbox;
   const int NS = P.S;
   const int n_pass = (NS + 63) >> 6;                    // more than 64 shadow samples: passes of 64 sample lanes
   Work wk;
@@ -480,20 +480,19 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
     const int x = B.x0 + zorder_x(qz);
     const int lr = B.lr0 + zorder_y(qz);
     const bool valid = in_task && lr < P.owned_rows && x < P.W;
-    const int y = band_global_row(lr < P.owned_rows ? lr : 0, P.band_rows, P.band_index, P.band_count);
+    const int y = band_global_row(P, lr < P.owned_rows ? lr : 0);
     Ray ray = primary_ray(P, x, y, a % P.aa_x, a / P.aa_x);
     f3 duc, eu;
     float dumax;
     {
       // sub-pixel rectangle of the task: the bounding box of its pixels (the global row of a packed row may jump at
       // a band boundary, and a run of the Z curve is no rectangle: take minima and maxima over the task's lanes)
-      const int yl = band_global_row(lr < P.owned_rows ? lr : (P.owned_rows > 0 ? P.owned_rows - 1 : 0), P.band_rows,
-                                     P.band_index, P.band_count);
+      const int yl = band_global_row(P, lr < P.owned_rows ? lr : (P.owned_rows > 0 ? P.owned_rows - 1 : 0));
       const float xmin = wave_min_pos((float)x), xmax = wave_max_pos((float)x), ymin = wave_min_pos((float)yl), ymax = wave_max_pos((float)yl);
-      const float Xlo = xmin * (float)P.aa_x - ((float)P.W * (float)P.aa_x) / 2.0f;
-      const float Xhi = (xmax * (float)P.aa_x + (float)(P.aa_x - 1)) - ((float)P.W * (float)P.aa_x) / 2.0f;
-      const float Ylo = (ymin * (float)P.aa_y - ((float)P.H * (float)P.aa_y) / 2.0f) * P.sy;
-      const float Yhi = ((ymax * (float)P.aa_y + (float)(P.aa_y - 1)) - ((float)P.H * (float)P.aa_y) / 2.0f) * P.sy;
+      const float Xlo = xmin * (float)P.aa_x - P.half_wx;
+      const float Xhi = (xmax * (float)P.aa_x + (float)(P.aa_x - 1)) - P.half_wx;
+      const float Ylo = (ymin * (float)P.aa_y - P.half_hy) * P.sy;
+      const float Yhi = ((ymax * (float)P.aa_y + (float)(P.aa_y - 1)) - P.half_hy) * P.sy;
       const float hx = 0.5f * (Xhi - Xlo), hy = 0.5f * (Yhi - Ylo);
       const f3 wc = mk(Xlo + hx, Ylo + hy, P.focal);
       const f3 r0 = mk(P.rot[0], P.rot[1], P.rot[2]), r1 = mk(P.rot[4], P.rot[5], P.rot[6]),
@@ -692,7 +691,7 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
     bool task_sph = P.nsph > 0 && !task_ok;
     if (task_ok) {
       const int ci = bins ? world_cell(P, start) : 0;
-      const float linf_l = norm_inf(light);
+      const float linf_l = P.light_inf;
       for (unsigned long long rem = litmask; rem != 0ull; ++ngroups) {
         const int jr = __builtin_ctzll(rem);
         const int cj = __builtin_amdgcn_readlane(ci, jr);
@@ -978,7 +977,7 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
     const int lr = B.lr0 + (lane >> 3);
     if (!COUNT && !PROF && (!coop || wave == 0) && lr < P.owned_rows && x < P.W) {      // the counting pass has no framebuffer
       const f3 c = mk(div_count(outc.x, aa, P.inv_aa), div_count(outc.y, aa, P.inv_aa), div_count(outc.z, aa, P.inv_aa));
-      const size_t o = (size_t)(P.out_global ? band_global_row(lr, P.band_rows, P.band_index, P.band_count) : lr) * P.W + x;
+      const size_t o = (size_t)(P.out_global ? band_global_row(P, lr) : lr) * P.W + x;
       P.out_argb[o] = pack_argb(c);
       if (P.out_rgb) P.out_rgb[o] = make_float4(c.x, c.y, c.z, 1.0f);
     }
