@@ -497,6 +497,7 @@ static void fill_params(const rt_ctx* c, const float rot[12], const float cam[3]
     // going first: 4096 and 2048 rows -> 64 px, 1024 and 512 rows -> 32 px), but not below 16 pixels.
     const int pt = wave_aa ? 64 / aa : 64;              // pixels per 64-ray task
     P->aa_magic = wave_aa ? (65536 + aa - 1) / aa : 65536;
+    P->aax_magic = (65536 + g.aa_x - 1) / g.aa_x;
     // workgroups the chip holds at once; a rank of a multi-GPU job leaves one slot per CU free (registers and LDS
     // for a workgroup of a collective's kernels), so that the gather of the previous frame can run beside it
     const int per_cu = wave_blocks_per_cu(g.band_count > 1 && !c->tune.full_grid);

@@ -38,11 +38,6 @@ constexpr int kPointSamples = 8;            // up to this many shadow samples, l
 constexpr int kScreenCell = 32;             // pixels per side of a screen cell of the primary-ray tile masks
 constexpr int kScreenCellLog = 5;
 
-__device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
-  return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
-         (unsigned)__builtin_amdgcn_readfirstlane((int)v);
-}
-
 // World cell of a shadow ray's start point (rt_bin_shadow bounds exactly the points that map to a cell)
 __device__ __forceinline__ int world_cell(const FrameParams& P, f3 s) {
   const int g1 = P.grid_g - 1;
@@ -481,7 +476,8 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
     const int lr = B.lr0 + zorder_y(qz);
     const bool valid = in_task && lr < P.owned_rows && x < P.W;
     const int y = band_global_row(P, lr < P.owned_rows ? lr : 0);
-    Ray ray = primary_ray(P, x, y, a % P.aa_x, a / P.aa_x);
+    const int ay = (a * P.aax_magic) >> 16;        // a / aa_x (a < 256)
+    Ray ray = primary_ray(P, x, y, a - ay * P.aa_x, ay);
     f3 duc, eu;
     float dumax;
     {
@@ -521,13 +517,15 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
       }
       if (COUNT) { xw[0]++; xw[1] += __popcll(Kp); }
       if (valid) {
-        for (unsigned long long m = Kp; m != 0ull; m &= m - 1ull) {
+        // (uniform64: a loop inside a divergent `if` otherwise keeps its wave-uniform mask in vector registers)
+        for (unsigned long long m = uniform64(Kp); m != 0ull; m &= m - 1ull) {
           const int i = __builtin_ctzll(m);
           const float4 c4 = t_c[i];
+          const f3 pc = xyz(t_pc[i]), qc = xyz(t_qc[i]);
           const float detA_recip = rcp_exact(detc(ndp, xyz(c4)));
           const float tt = c4.w * detA_recip;
-          const float u = detc(ndp, xyz(t_pc[i])) * detA_recip;
-          const float v = detc(ndp, xyz(t_qc[i])) * detA_recip;
+          const float u = detc(ndp, pc) * detA_recip;
+          const float v = detc(ndp, qc) * detA_recip;
           // the reference visits the triangles in their ORIGINAL order and replaces the hit only for a strictly smaller
           // t (kernels.cl:120): of equal t the lowest original index stays — whatever order the tiles come in
           const int oi = __float_as_int(t_or[i].w);
@@ -633,7 +631,7 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
             Kb &= ~ballot(task_bound(Tb, s0, D0, es, ed, 2e-6f * dl, 0.0f, dl).clear);
           }
           if (act)
-            for (unsigned long long m = Kb; m != 0ull; m &= m - 1ull) {
+            for (unsigned long long m = uniform64(Kb); m != 0ull; m &= m - 1ull) {
               const int i = __builtin_ctzll(m);
               const float4 e14 = t_e1[i];
               const f3 v0 = xyz(t_v0[i]), e1 = xyz(e14), e2 = xyz(t_e2[i]), c = xyz(t_c[i]);
@@ -807,6 +805,7 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
       MESH_STAMP(5)
       if (COUNT) { xw[2]++; xw[3] += __popcll(K); }
       if (K == 0ull) return;
+      K = uniform64(K);                                            // the loops over K then run on the scalar unit
       unsigned long long need = 0ull;                              // level 2, lane = surface point; bit = tile triangle
       // with one or two samples per point the bound costs more than the samples: test every candidate
       if (NS <= kDirectSamples) need = mymask;

@@ -420,9 +420,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
     const int a = lnA - pA * aa;               // AA sample index dy*rx+dx, kernels.cl:395
     const int x = x0 + pj;
     const bool valid = x < P.W && pA < PT;
-    Ray ray = primary_ray(P, x, y, a % P.aa_x, a / P.aa_x);
+    const int ay = (a * P.aax_magic) >> 16;        // a / aa_x (a < 256)
+    Ray ray = primary_ray(P, x, y, a - ay * P.aa_x, ay);
     bool lit = false, secondary = false;
-    const unsigned long long Kp = Kp_job;      // triangles a primary ray of this job may hit
+    // triangles a primary ray of this job may hit (read back through readfirstlane: the set is the same in every lane, and
+    // the loop over it then runs on the scalar unit)
+    const unsigned long long Kp = uniform64(Kp_job);
     if (valid) {
       if (CULL) closest_hit_primary_masked(S, P, ray, Kp, sph_job);
       else closest_hit_primary<false>(S, P, ray, wk);

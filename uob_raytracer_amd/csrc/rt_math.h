@@ -52,9 +52,13 @@ __device__ __forceinline__ float rcp_newton(float x, int steps) {
 // mismatches are denormal x and |x| >= 2^126).  For zero, denormal, infinite or NaN x the refinement
 // returns NaN, which is the cue to fall back to the division; |x| >= 2^126 cannot occur for scenes that
 // pass rt_init's coordinate bound (|coordinate| <= 2^16, rt_device.h kMaxCoordinate).
+// The fallback sits behind a WAVE-UNIFORM branch (a ballot): written as a plain per-lane `if`, the compiler computes
+// the division for every call and selects (12 more instructions per triangle test).
 __device__ __forceinline__ float rcp_exact(float x) {
   float r = rcp_newton(x, 1);
-  if (r != r) r = 1.0f / x;
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(r != r) != 0ull, 0)) {
+    if (r != r) r = 1.0f / x;
+  }
   return r;
 }
 

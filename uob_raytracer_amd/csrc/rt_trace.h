@@ -173,10 +173,11 @@ __device__ inline void closest_hit_primary_masked(const LdsScene& S, const Frame
   for (; mask != 0ull; mask &= mask - 1ull) {
     const int i = __builtin_ctzll(mask);
     const float4 c4 = S.c[i];
+    const f3 pc = xyz(S.pc[i]), qc = xyz(S.qc[i]);     // all three records requested before the first is used
     const float detA_recip = rcp_exact(detc(nd, xyz(c4)));
     const float t = c4.w * detA_recip;
-    const float u = detc(nd, xyz(S.pc[i])) * detA_recip;
-    const float v = detc(nd, xyz(S.qc[i])) * detA_recip;
+    const float u = detc(nd, pc) * detA_recip;
+    const float v = detc(nd, qc) * detA_recip;
     if (t < current_t && u >= 0 && v >= 0 && (u + v) <= 1 && t >= 0) {
       best = i; bu = u; bv = v; current_t = t;
     }

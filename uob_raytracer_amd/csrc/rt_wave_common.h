@@ -35,6 +35,13 @@ __device__ __forceinline__ float bsqrt(float x) { return __builtin_amdgcn_sqrtf(
 __device__ __forceinline__ float norm_inf(f3 a) { return fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fabsf(a.z)); }
 __device__ __forceinline__ float max_abs3(float a, float b, float c) { return fmaxf(fmaxf(fabsf(a), fabsf(b)), fabsf(c)); }
 
+// A 64-bit value that is the same in every lane, read back through the scalar unit: a loop over a wave-uniform mask that
+// sits inside a divergent `if` otherwise keeps the mask (and runs its bookkeeping) in vector registers
+__device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
+  return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+         (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+
 // Wave-wide reductions.  The result is the same in every lane; readfirstlane tells the compiler so
 // (otherwise everything derived from it — the candidate masks, the loops over them — is treated as
 // divergent and kept in VGPRs with exec-mask loops).
