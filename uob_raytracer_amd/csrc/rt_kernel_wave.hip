@@ -34,6 +34,7 @@
 // Arithmetic is the reference's, operation for operation (rt_math.h): results are bit-identical to the
 // generic kernel and to the CPU oracle.
 #define RT_SPHERES_IN_LDS
+#define RT_RNG_JUMP_IN_LDS
 #include "rt_wave_common.h"
 
 #ifndef RT_OPT_SPHJOB
@@ -271,6 +272,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
   // ---- stage the triangle list once per workgroup ---------------------------------------------------
   stage_triangles(P, lds, tid, 64 * kWavesPerBlock, st);
   stage_spheres(P, tid);
+  stage_rng_jump(tid);
   int* sidx = reinterpret_cast<int*>(lds + kLdsRecords * st);         // shadow-casting triangles, in order
   if (wave == 0) {                                                    // n <= 64 on this path (supports())
     const bool casts = (lane < n) && (P.colors[lane < n ? lane : 0].w != -1.0f);   // glass casts no shadow, :247
@@ -294,6 +296,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
   const int aa = P.aa_x * P.aa_y;                                     // a power of two <= 64 (supports())
   const int PT = 64 / aa;                                             // pixels per task (lanes >= PT * aa idle)
   const int GP = PT < kRngPixels ? PT : kRngPixels;                   // pixels per RNG group
+  const int gp_magic = (65536 + GP - 1) / GP;                         // q / GP == (q * gp_magic) >> 16 for q < 64
   const f3 light = mk(P.light[0], P.light[1], P.light[2]);
   const float hbox = P.hbox;                                          // |crush()| <= range/2, :51
   const unsigned long long tri_lanes = ns == 64 ? ~0ull : ((1ull << ns) - 1ull);
@@ -340,6 +343,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
   // wave for microseconds), fewer as it runs out, single jobs over the last stretch, where balance matters more.
   const int per_wave = 8 * (int)gridDim.x * kWavesPerBlock;
   int next_job = -1, chunk_left = 0;                    // the rest of the last hand-out, still to do
+  unsigned int listed = 0u;                             // bit i: job i of the rest of the hand-out is on last frame's list
   int chunk = P.njobs > 2 * per_wave ? RT_CHUNK : (P.njobs > per_wave ? 2 : 1);      // size of the next hand-out
   for (;;) {
   int job = 0;
@@ -352,11 +356,18 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
     if (job < 0 || job >= P.njobs) continue;
   } else {
     if (chunk_left > 0) {
-      job = next_job; next_job += kJobHeads; --chunk_left;
+      job = next_job; next_job += kJobHeads; --chunk_left; listed >>= 1;
     } else {
       if (lane == 0) job = (int)atomicAdd(P.job_counter + head * kJobHeadStride, (unsigned int)chunk);
       job = __builtin_amdgcn_readfirstlane(job) * kJobHeads + head;
       next_job = job + kJobHeads; chunk_left = chunk - 1;
+      // which jobs of this hand-out are on last frame's list (phase A takes care of those): ONE load for the hand-out,
+      // lane i asking for job i, instead of a dependent load in front of every job
+      listed = 0u;
+      if (n_heavy != 0u) {
+        const int jl = job + lane * kJobHeads;
+        listed = (unsigned int)ballot(lane <= chunk_left && jl < P.njobs && P.heavy_flags[jl] >= P.heavy_gen);
+      }
       // what this head has left decides the next hand-out: RT_CHUNK jobs while more than ~16 per wave remain in all,
       // two while more than ~8, then one
       const int left = P.njobs - next_job;
@@ -373,7 +384,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
       if (!found) break;
       continue;
     }
-    if (n_heavy != 0u && P.heavy_flags[job] >= P.heavy_gen) continue;     // listed: taken care of by phase A
+    if ((listed & 1u) != 0u) continue;                                    // listed: taken care of by phase A
   }
   RT_STAMP(7)                               // 7: waiting for the hand-out (PROF builds)
   const unsigned long long job_t0 = lpt ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -581,8 +592,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
       const int cnt_s = NS - first_s < 64 ? NS - first_s : 64;         // samples in it
       const unsigned long long act = (!MULTI || cnt_s == 64) ? active : ((1ull << cnt_s) - 1ull);
       // xorshift streams of the GP pixels of this group: lnC c -> (pixel c/3, component c%3), :319,:331
-      if (lnC < 3 * GP) {
-        const int pp = lnC / 3, comp = lnC % 3;
+      // lane -> (segment, pixel, component): kRngSegs lanes share a stream, lane `seg` writing samples [13 seg, 13 seg + 13)
+      const int q3 = lnC / 3, comp = lnC - 3 * q3;
+      const int seg = (q3 * gp_magic) >> 16, pp = q3 - seg * GP;         // q3 / GP, q3 % GP
+      if (seg < kRngSegs) {
         uint32_t* dst = L.rng + pp * kRngStride + comp;
         uint32_t s;
         if (!MULTI || pass == 0) {
@@ -592,7 +605,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
         } else {
           s = dst[63 * 4];                                               // the stream goes on where the last pass left it
         }
-        for (int it = 0; it < cnt_s; ++it) { s = xorshift(s); dst[it * 4] = s; }
+        if (seg > 0) s = rng_jump(s, seg);
+        const int it0 = seg * kRngSegLen;
+#pragma unroll 1
+        for (int j = 0; j < kRngSegLen; ++j) { s = xorshift(s); if (it0 + j < cnt_s) dst[(it0 + j) * 4] = s; }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
