@@ -659,10 +659,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
       // direct_light's running sum (:335): the same term added once per unblocked sample, in sequence.
       // Most tasks have every lit lnD fully lit: then the adds need no per-lnD predicate.
       float total = 0.0f;
+      // (eight adds per trip: one add per trip is a taken branch per add, and the chain is on every task's critical path)
       if (ballot(lit && unshadowed != NS) == 0ull) {
+#pragma unroll 8
         for (int i = 0; i < NS; ++i) total += term;
       } else {
         if (unshadowed < NS) total += 0.0f * term;        // a blocked sample adds 0*term (NaN/inf-faithful)
+#pragma unroll 8
         for (int i = 0; i < NS; ++i) if (i < unshadowed) total += term;
       }
       if (lit) {
