@@ -500,7 +500,7 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
     }
     // can any primary ray of the task touch a sphere at all? (else the quadratic tests per ray are skipped)
     const bool sph_task = P.nsph > 0 && (!(dumax < 1e30f) ||
-                          ballot(sphere_bundle_maybe(P, mk(P.cam[0], P.cam[1], P.cam[2]), 0.0f, duc, bsqrt(dot3(duc, duc)),
+                          ballot(sphere_bundle_maybe(P, lane, mk(P.cam[0], P.cam[1], P.cam[2]), 0.0f, duc, bsqrt(dot3(duc, duc)),
                                                      1.0001f * bsqrt(dot3(eu, eu)), false)) != 0ull);
     MESH_STAMP(0)
     float current_t = RT_MAXFLOAT, bu = 0.f, bv = 0.f;
@@ -708,7 +708,7 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
         if (P.nsph > 0) {     // may any shadow ray of the group touch a shadow-casting sphere?
           const float hh_g = 1.002f * hbox + 2e-6f * (dlen_max + hbox);
           const float s0inf = norm_inf(s0), d0inf = norm_inf(D0);
-          task_sph = task_sph || ballot(sphere_bundle_maybe(P, s0, 1.001f * es + 2e-6f * (s0inf + es), D0, rl(dlen, jr) * 1.000001f,
+          task_sph = task_sph || ballot(sphere_bundle_maybe(P, lane, s0, 1.001f * es + 2e-6f * (s0inf + es), D0, rl(dlen, jr) * 1.000001f,
                                                             1.7321f * (1.001f * ed + 2e-6f * d0inf + hh_g), true)) != 0ull;
         }
         if (lane == 0) {

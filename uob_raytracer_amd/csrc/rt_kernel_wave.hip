@@ -265,6 +265,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
   __shared__ float4 lds_fix[STRIDE ? wave_fixed_lds_float4<STRIDE ? STRIDE : 4, CULL>() : 1];
   float4* const lds = STRIDE ? lds_fix : lds_dyn;
   const int tid = threadIdx.x;
+  // (The compiler cannot know that tid >> 6 is the same in all 64 lanes: the queue head, the job id and everything derived
+  // from them count as per-lane values and live in vector registers.  Declaring the wave index uniform with readfirstlane
+  // moves them to the scalar file, which is the fuller one: 18 more scalar spills, 3.23 -> 3.25 ms.  Left as it is.)
   const int wave = tid >> 6, lane = tid & 63;
   const int n = P.n, ns = P.n_shadow;
   const int st = STRIDE ? STRIDE : n, sst = STRIDE ? STRIDE : ns;     // record-array strides
@@ -419,7 +422,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
     if (dumax < 1e30f) Kp_job &= ~ballot(clear);
     // ... and whether any of them can touch a sphere at all (else the two quadratic tests per ray are skipped)
     if (RT_OPT_SPHJOB && P.nsph > 0 && dumax < 1e30f)
-      sph_job = ballot(sphere_bundle_maybe(P, mk(P.cam[0], P.cam[1], P.cam[2]), 0.0f, duc, bsqrt(dot3(duc, duc)),
+      sph_job = ballot(sphere_bundle_maybe(P, lane, mk(P.cam[0], P.cam[1], P.cam[2]), 0.0f, duc, bsqrt(dot3(duc, duc)),
                                            1.0001f * bsqrt(dot3(eu, eu)), false)) != 0ull;
   }
   RT_STAMP(0)                               // 0: job set-up (primary-ray bounds of the job)
@@ -538,7 +541,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
         if (all_sane && es < 1e30f && ed < 1e30f) {                    // finite, non-degenerate
           const float hh_task = 1.002f * hbox + 2e-6f * (dlen_max + hbox);
           if (RT_OPT_TASKSPH && P.nsph > 0)       // every sample direction lies within sqrt(3) (ed + hh) of D0, every start within es of s0
-            task_sph = ballot(sphere_bundle_maybe(P, s0, es, D0, dlen0, 1.7321f * (1.001f * ed + hh_task), true)) != 0ull;
+            task_sph = ballot(sphere_bundle_maybe(P, lane, s0, es, D0, dlen0, 1.7321f * (1.001f * ed + hh_task), true)) != 0ull;
           TriLane T1;
           T1.v0 = xyz(SC.v0[(lnB < ns ? lnB : 0)]); T1.e1 = xyz(SC.e1[(lnB < ns ? lnB : 0)]); T1.e2 = xyz(SC.e2[(lnB < ns ? lnB : 0)]); T1.c = xyz(SC.c[(lnB < ns ? lnB : 0)]);
           T1.c1 = norm1(T1.c); T1.e1_1 = norm1(T1.e1); T1.e2_1 = norm1(T1.e2);

@@ -178,9 +178,9 @@ __device__ inline void closest_hit_primary_masked(const LdsScene& S, const Frame
     const float t = c4.w * detA_recip;
     const float u = detc(nd, pc) * detA_recip;
     const float v = detc(nd, qc) * detA_recip;
-    if (t < current_t && u >= 0 && v >= 0 && (u + v) <= 1 && t >= 0) {
-      best = i; bu = u; bv = v; current_t = t;
-    }
+    // (& instead of &&: five compares and four selects, no branch around them)
+    const bool hit = (t < current_t) & (u >= 0) & (v >= 0) & ((u + v) <= 1) & (t >= 0);
+    best = hit ? i : best; bu = hit ? u : bu; bv = hit ? v : bv; current_t = hit ? t : current_t;
   }
   if (best >= 0) {
     ray.tri = best;
