@@ -502,10 +502,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
     const f3 start = ray.P + 0.0001f * dir;
     const float radius_sq = dir.x * dir.x + dir.y * dir.y + dir.z * dir.z;
     const float term = (16.0f * fmaxf(dot3(dir, ray.N), 0.0f)) / (4.0f * 3.14159274f * radius_sq);
-    __builtin_amdgcn_wave_barrier();
-    L.h0[lnB] = make_float4(start.x, start.y, start.z, radius_sq);
-    L.h1[lnB] = make_float4(dir.x, dir.y, dir.z, 0.f);
-    __builtin_amdgcn_wave_barrier();
 
     // ---- phase 3: shadows of the lit surface points ---------------------------------------------------
     int unshadowed = NS;                        // samples of this lnB's surface point that reach the light
@@ -585,6 +581,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
 
     RT_STAMP(3)                             // 3: level 2
     const int lnC = opaque(lane);
+    // level 3 reads the surface points lane = sample: they go to LDS only for the tasks that get there
+    if (work != 0ull) {
+      __builtin_amdgcn_wave_barrier();
+      L.h0[lnC] = make_float4(start.x, start.y, start.z, radius_sq);
+      L.h1[lnC] = make_float4(dir.x, dir.y, dir.z, 0.f);
+      __builtin_amdgcn_wave_barrier();
+    }
     // level 3 / brute force: the reference's sample test, one surface point at a time
     const int GL = GP * aa;                     // lanes per RNG group
     for (int g = 0; g * GP < PT && work != 0ull; ++g) {
