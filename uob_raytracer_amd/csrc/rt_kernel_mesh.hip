@@ -20,6 +20,7 @@
 // (64-ray task, triangle) plus the few real tests.  Mirror / glass bounce rays run in rounds, the workgroup's four
 // tasks together, every round streaming all tiles through LDS with the same lane = triangle bound in front.
 #define RT_SPHERES_IN_LDS
+#define RT_RNG_JUMP_IN_LDS
 #include "rt_wave_common.h"
 
 namespace uobrt {
@@ -131,8 +132,10 @@ struct BlockGeom {
 // `cnt` samples that follow the first `skip` ones (passes of 64 samples when there are more than 64)
 __device__ __forceinline__ void generate_streams(const FrameParams& P, const MeshWaveLds& L, int lane, int GP, int skip, int cnt,
                                                  const BlockGeom& B, int k, int first_p) {
-  if (lane < 3 * GP) {
-    const int pp = lane / 3, comp = lane % 3;
+  // kRngSegs lanes per stream, lane `seg` writing samples [13 seg, 13 seg + 13) from the jumped state (rt_wave_common.h)
+  const int q3 = lane / 3, comp = lane - 3 * q3;
+  const int seg = GP == 4 ? q3 >> 2 : (GP == 2 ? q3 >> 1 : (GP == 1 ? q3 : q3 / GP)), pp = q3 - seg * GP;
+  if (seg < kRngSegs) {
     const int qq = B.q(k, first_p + pp) < 64 ? B.q(k, first_p + pp) : 63;      // a pixel past the block is never lit
     const int px = B.x0 + zorder_x(qq);
     const int py = band_global_row(P, B.lr0 + zorder_y(qq));
@@ -141,7 +144,10 @@ __device__ __forceinline__ void generate_streams(const FrameParams& P, const Mes
     uint32_t s = xorshift(seed);
     uint32_t* dst = L.rng + pp * kRngStride + comp;
     for (int it = 0; it < skip; ++it) s = xorshift(s);
-    for (int it = 0; it < cnt; ++it) { s = xorshift(s); dst[it * 4] = s; }
+    if (seg > 0) s = rng_jump(s, seg);
+    const int it0 = seg * kRngSegLen;
+#pragma unroll 1
+    for (int j = 0; j < kRngSegLen; ++j) { s = xorshift(s); if (it0 + j < cnt) dst[(it0 + j) * 4] = s; }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -385,6 +391,7 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
   // first frame goes from the middle rows outwards).  No pixel depends on the order.
   __shared__ int s_job;
   stage_spheres(P, tid);                               // (the job loop's first barrier publishes them)
+  stage_rng_jump(tid);
   const int wgx_n = (P.W + 15) / 16, wgy_n = (P.owned_rows + 15) / 16, n_jobs = wgx_n * wgy_n;
   const int n_queue = P.mesh_order != nullptr ? (int)P.mesh_queue_len[0] : n_jobs;
   const int wg_mid = (wgy_n + 1) >> 1;
@@ -955,7 +962,8 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
     if (lit) {
       float total = 0.0f;
       if (unshadowed < NS) total += 0.0f * term;
-      for (int i = 0; i < NS; ++i) if (i < unshadowed) total += term;
+#pragma unroll 8
+      for (int i = 0; i < NS; ++i) if (i < unshadowed) total += term;       // (one add per trip = one taken branch per add)
       const float l = 0.5f + div_count(total, NS, P.inv_S);
       if (secondary) { const float kk = 0.9f * l; contrib = mk(kk * ray.col.x, kk * ray.col.y, kk * ray.col.z); }
       else contrib = mk(ray.col.x * l, ray.col.y * l, ray.col.z * l);
