@@ -161,6 +161,14 @@ int rt_debug_trace_rays(rt_ctx* ctx, int32_t what, const float* rays6, const flo
  * RT_E_UNSUPPORTED when the context keeps no such state (n <= 64, RT_FLAG_PLAIN_ORDER, generic kernel).          */
 int rt_debug_block_costs(rt_ctx* ctx, uint32_t* out, int32_t cap);
 
+/* Diagnostic, wave kernel (n <= 64), contexts created with UOB_RT_TIMELINE=1 in the environment: how the persistent
+ * waves of the most recent frame spent the kernel's duration, from the 100 MHz s_memrealtime clock.
+ *   out[0] waves   out[1] first wave start   out[2] last wave end   out[3] sum of starts   out[4] sum of ends
+ *   out[5] jobs done by all waves   out[6] most jobs done by one wave   out[7] length of the expensive-job list the frame started from
+ * (start = a wave's first request for a job, end = its exit; mean idle tail = out[2] - out[4]/out[0]).
+ * RT_E_UNSUPPORTED when the context was not created with the knob set or its last frame ran on another kernel. */
+int rt_debug_wave_timeline(rt_ctx* ctx, uint64_t out[8]);
+
 /* On-device self test of the exact-reciprocal building block (rt_math.h rcp_newton): sweeps all 2^32
  * FP32 patterns and compares v_rcp_f32 + 1/2 Newton steps with the correctly rounded 1.0f/x.
  * out[0],out[1] = mismatches (1-step, 2-step) for 2^-100 <= |x| <= 2^100; out[2],out[3] = mismatches for

@@ -79,6 +79,7 @@ struct Tuning {
   bool plain_order = false;   // RT_FLAG_PLAIN_ORDER or UOB_RT_PLAIN_ORDER
   bool full_grid = false;     // UOB_RT_FULL_GRID: a rank of a multi-GPU job fills every wave slot too
   bool phase_profile = false; // UOB_RT_PHASE_PROFILE: rt_count_executed returns s_memtime shares per phase
+  bool timeline = false;      // UOB_RT_TIMELINE: the wave kernel records when its waves start and end (rt_debug_wave_timeline)
   int mask_debug = 0;         // UOB_RT_MASK_DEBUG: mesh kernel, switch single tile-mask stages off (fault isolation)
 };
 
@@ -97,6 +98,9 @@ struct rt_ctx {
   // wave kernel: last frame's expensive jobs go first (rt_device.h FrameParams::heavy_*); two lists, used in turn
   unsigned int *d_heavy[2] = {nullptr, nullptr}, *d_heavy_flags = nullptr;
   int heavy_cap = 0, heavy_phase = 0;
+  bool timeline_valid = false;   // the last frame left one (start, end, jobs) record per wave in d_timeline
+  uint64_t* d_timeline = nullptr;
+  size_t timeline_waves = 0;
   uint32_t heavy_gen = 0;
   float4* d_records = nullptr;     // staged records in HBM for meshes beyond one LDS stage
   // mesh kernel (n > 64): the scene once more, reordered so that every 64-triangle tile is spatially compact (large
@@ -165,6 +169,7 @@ static Tuning read_tuning(const rt_config& cfg) {
   t.plain_order = (cfg.flags & RT_FLAG_PLAIN_ORDER) != 0 || getenv("UOB_RT_PLAIN_ORDER") != nullptr;
   t.full_grid = getenv("UOB_RT_FULL_GRID") != nullptr;
   t.phase_profile = getenv("UOB_RT_PHASE_PROFILE") != nullptr;
+  t.timeline = getenv("UOB_RT_TIMELINE") != nullptr;
   if (const char* e = getenv("UOB_RT_MASK_DEBUG")) t.mask_debug = atoi(e);
   return t;
 }
@@ -585,6 +590,19 @@ static int launch_frame(rt_ctx* c, const float rot[12], const float cam[3], cons
       P.heavy_cap = P.njobs / 8 < c->heavy_cap ? P.njobs / 8 : c->heavy_cap;
       c->heavy_phase = cur;
     }
+    c->timeline_valid = false;
+    if (c->tune.timeline) {                 // diagnostic: the shipped kernel, with its per-wave start / end stamps
+      const size_t waves = (size_t)P.wave_blocks * 4;
+      if (!c->d_timeline) {
+        if (hipMalloc(&c->d_timeline, waves * 3 * sizeof(uint64_t)) != hipSuccess) { set_error("hipMalloc failed (timeline)"); return RT_E_NOMEM; }
+        c->timeline_waves = waves;
+      }
+      if (c->timeline_waves >= waves) {
+        HIP_TRY(hipMemsetAsync(c->d_timeline, 0, c->timeline_waves * 3 * sizeof(uint64_t), stream));
+        P.counters = reinterpret_cast<unsigned long long*>(c->d_timeline);
+        c->timeline_valid = true;
+      }
+    }
     launch_wave(P, !(c->cfg.flags & RT_FLAG_NO_CULL), false, stream);
   } else if (wave_paths && !(c->cfg.flags & RT_FLAG_NO_CULL) && mesh_kernel_supports(P)) {
     use_tiled_scene(c, &P);
@@ -777,6 +795,32 @@ int rt_count_executed(rt_ctx* c, const float rot[12], const float cam[3], const 
   return RT_OK;
 }
 
+int rt_debug_wave_timeline(rt_ctx* c, uint64_t out[8]) {
+  if (!c || !out) { set_error("NULL argument"); return RT_E_INVALID; }
+  if (!c->kids.empty()) c = c->kids[0];
+  if (!c->tune.timeline || !c->timeline_valid) {
+    set_error("rt_debug_wave_timeline: needs UOB_RT_TIMELINE=1 at rt_init and a frame rendered by the wave kernel");
+    return RT_E_UNSUPPORTED;
+  }
+  DeviceGuard guard;
+  HIP_TRY(hipSetDevice(c->device));
+  if (c->timed) HIP_TRY(hipEventSynchronize(c->ev1));
+  std::vector<uint64_t> rec(c->timeline_waves * 3);
+  HIP_TRY(hipMemcpy(rec.data(), c->d_timeline, rec.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  for (int q = 0; q < 8; ++q) out[q] = 0;
+  out[1] = ~0ull;
+  for (size_t w = 0; w < c->timeline_waves; ++w) {
+    const uint64_t t0 = rec[3 * w], t1 = rec[3 * w + 1], jobs = rec[3 * w + 2] & 0xffffffffull;
+    if (t1 == 0) continue;                  // a slot no wave of the grid wrote
+    out[7] = rec[3 * w + 2] >> 32;
+    out[0] += 1; out[3] += t0; out[4] += t1; out[5] += jobs;
+    if (t0 < out[1]) out[1] = t0;
+    if (t1 > out[2]) out[2] = t1;
+    if (jobs > out[6]) out[6] = jobs;
+  }
+  return RT_OK;
+}
+
 int rt_debug_trace_rays(rt_ctx* c, int32_t what, const float* rays6, const float* radius_sq, int64_t nray,
                         int32_t* out_tri, float* out10) {
   if (!c || !rays6 || !out_tri || nray < 0) { set_error("NULL argument"); return RT_E_INVALID; }
@@ -875,7 +919,7 @@ void rt_destroy(rt_ctx* c) {
   hipFree(c->d_verts); hipFree(c->d_normals); hipFree(c->d_colors);
   hipFree(c->d_argb); hipFree(c->d_rgb); hipFree(c->d_counters); hipFree(c->d_records); hipFree(c->d_jobctr);
   hipFree(c->d_screen_masks); hipFree(c->d_world_masks); hipFree(c->d_world_occ);
-  hipFree(c->d_heavy[0]); hipFree(c->d_heavy[1]); hipFree(c->d_heavy_flags);
+  hipFree(c->d_heavy[0]); hipFree(c->d_heavy[1]); hipFree(c->d_heavy_flags); hipFree(c->d_timeline);
   hipFree(c->d_mesh_cost); hipFree(c->d_mesh_order); hipFree(c->d_spheres);
   hipFree(c->d_verts_m); hipFree(c->d_normals_m); hipFree(c->d_colors_m); hipFree(c->d_orig); hipFree(c->d_tile_box);
   delete c;

@@ -341,6 +341,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
     const unsigned int pjobs = P.heavy_prev_state[4];
     if (pjobs != 0u) heavy_thr = (unsigned long long)P.heavy_factor4 * (psum / pjobs) / 4ull;    // per TASK
   }
+  // diagnostic (UOB_RT_TIMELINE): when this wave starts asking for jobs and how many it gets; kept in the padding words of
+  // the second pixel's RNG scratch, not in registers
+  const bool timeline = !COUNT && !PROF && P.counters != nullptr;
+  unsigned long long* const tls = reinterpret_cast<unsigned long long*>(L.rng + kRngStride + 256);
+  if (timeline && lane == 0) { tls[0] = __builtin_amdgcn_s_memrealtime(); tls[1] = 0ull; }
   bool phase_a = n_heavy != 0u;
   // Several jobs per hand-out while the queue is long (a hand-out is a returning device-scope atomic that stalls its
   // wave for microseconds), fewer as it runs out, single jobs over the last stretch, where balance matters more.
@@ -390,6 +395,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
     if ((listed & 1u) != 0u) continue;                                    // listed: taken care of by phase A
   }
   RT_STAMP(7)                               // 7: waiting for the hand-out (PROF builds)
+  if (timeline && lane == 0) tls[1] += 1ull;
   const unsigned long long job_t0 = lpt ? __builtin_amdgcn_s_memtime() : 0ull;
   // Rows are handed out from the middle of the rank's rows outwards: segments differ 10x in cost, and the kernel
   // ends when the last job does, so the last jobs should be cheap ones — the top and bottom rows of a view
@@ -717,6 +723,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
   if (lpt && lane == 0) {
     atomicAdd(reinterpret_cast<unsigned long long*>(P.heavy_new_state + 2), cost_acc[0]);
     atomicAdd(P.heavy_new_state + 4, (unsigned int)cost_acc[1]);
+  }
+  if (timeline && lane == 0) {
+    const unsigned long long t1 = __builtin_amdgcn_s_memrealtime(), t0 = tls[0];
+    unsigned long long* const rec = P.counters + 3 * (size_t)(blockIdx.x * kWavesPerBlock + wave);   // one record per wave
+    rec[0] = t0; rec[1] = t1; rec[2] = tls[1] | ((unsigned long long)n_heavy << 32);   // (+ the length of the list this frame started from)
   }
   if (PROF) {
     if (lane == 0) for (int q = 0; q < 8; ++q) atomicAdd(&P.counters[q], prof[q]);

@@ -17,7 +17,7 @@ EXPORTS = (
     "rt_abi_version", "rt_last_error", "rt_config_default", "rt_config_owned_rows", "rt_init", "rt_render",
     "rt_render_device", "rt_count_work", "rt_count_executed", "rt_last_kernel_ms", "rt_destroy", "rt_scene_cornell_box",
     "rt_scene_load_obj", "rt_scene_load_obj_ex", "rt_triangle_compute_normal", "rt_scene_pack", "rt_rotation_matrix",
-    "rt_selftest_rcp", "rt_debug_trace_rays", "rt_debug_block_costs",
+    "rt_selftest_rcp", "rt_debug_trace_rays", "rt_debug_block_costs", "rt_debug_wave_timeline",
 )
 
 _lib = None
@@ -55,6 +55,7 @@ def lib():
         L.rt_scene_load_obj_ex.argtypes = [C.c_char_p, fp, C.c_float, fp, C.POINTER(abi.RtTriangle), C.c_int32]
         L.rt_debug_trace_rays.argtypes = [vp, C.c_int32, fp, fp, C.c_int64, C.POINTER(C.c_int32), fp]
         L.rt_debug_block_costs.argtypes = [vp, C.POINTER(C.c_uint32), C.c_int32]
+        L.rt_debug_wave_timeline.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.rt_triangle_compute_normal.argtypes = [C.POINTER(abi.RtTriangle)]
         L.rt_triangle_compute_normal.restype = None
         L.rt_scene_pack.argtypes = [C.POINTER(abi.RtTriangle), C.c_int32, fp, fp, fp]
@@ -229,6 +230,16 @@ class RayTracer:
         _check(lib().rt_debug_trace_rays(self._h, abi.RT_TRACE_CLOSEST_HIT, _fp(rays), None, rays.shape[0],
                                          tri.ctypes.data_as(C.POINTER(C.c_int32)), _fp(out)))
         return tri, out
+
+    def wave_timeline(self):
+        """Wave kernel, context created with UOB_RT_TIMELINE=1: start / end statistics of the last frame's persistent waves
+        in 100 MHz ticks (rt_debug_wave_timeline)."""
+        out = (C.c_uint64 * 8)()
+        _check(lib().rt_debug_wave_timeline(self._h, out))
+        n = max(int(out[0]), 1)
+        first, last = int(out[1]), int(out[2])
+        return {"waves": int(out[0]), "span_us": (last - first) / 100.0, "mean_start_us": (int(out[3]) / n - first) / 100.0,
+                "mean_idle_tail_us": (last - int(out[4]) / n) / 100.0, "jobs": int(out[5]), "max_jobs_per_wave": int(out[6]), "listed_jobs": int(out[7])}
 
     def block_costs(self):
         """Mesh kernel: s_memtime ticks of every 16x16-pixel block of the last frame, [rows/16, W/16] (rt_debug_block_costs)."""
