@@ -68,8 +68,9 @@ def build_scene(workload, rt):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=20,
+                    help="untimed frames first (the device needs ~15 frames / 50 ms of load to reach its clocks, profiles/r02_wave_timeline.txt)")
     ap.add_argument("--workload", default="headline", choices=list(WORKLOADS))
     ap.add_argument("--band-rows", type=int, default=32)
     ap.add_argument("--cpu-sample-pixels", type=int, default=0, help="0 = auto (about 10-30 s of CPU work)")

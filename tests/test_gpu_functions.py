@@ -55,3 +55,25 @@ def test_functions_on_a_mesh_against_the_oracle(n_lon, n_lat, scene, oracle, vec
     hit = tri != -1
     assert np.array_equal(out[hit].view(np.uint32), o_out[hit].view(np.uint32))
     assert (tri >= 26).any()                                           # some rays hit the mesh
+
+
+def test_wave_timeline_diagnostic(scene, monkeypatch):
+    """UOB_RT_TIMELINE (read once in rt_init): the shipped wave kernel leaves one (start, end, jobs) record per wave; the
+    frame is the same with and without, and a context created without the knob refuses the query."""
+    cfg = abi.make_config(width=512, height=256, aa_x=2, aa_y=2, shadow_samples=16)
+    rot, cam, light = rt.rotation_matrix(0.1, 0.0), [0, 0, -3.2], [0, -0.5, -0.7]
+    plain = rt.RayTracer(cfg, scene)
+    ref = plain.render(rot, cam, light, 1100.0)
+    with pytest.raises(rt.RtError):
+        plain.wave_timeline()
+    plain.close()
+    monkeypatch.setenv("UOB_RT_TIMELINE", "1")
+    tr = rt.RayTracer(cfg, scene)
+    monkeypatch.delenv("UOB_RT_TIMELINE")
+    for _ in range(3):
+        got = tr.render(rot, cam, light, 1100.0)
+        t = tr.wave_timeline()
+        assert np.array_equal(got, ref)
+        assert t["waves"] > 0 and t["span_us"] > 0 and 0 <= t["mean_idle_tail_us"] <= t["span_us"]
+        assert t["jobs"] >= 512 * 256 // 64 and t["max_jobs_per_wave"] >= 1      # every job taken by exactly one wave
+    tr.close()
