@@ -8,7 +8,7 @@ for bc in [int(v) for v in (sys.argv[1:] or ['1', '2'])]:
     tr = rt.RayTracer(cfg, rt.Scene.cornell_box())
     buf = torch.empty((tr.rows, 4096), dtype=torch.int32, device="cuda")
     ts = []
-    for i in range(10):
+    for i in range(45):      # (the device needs ~15 frames to reach its clocks)
         tr.render_device(rt.rotation_matrix(0, 0), [0, 0, -3.2], [0, -0.5, -0.7], 1100.0 * 16, buf.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
-        torch.cuda.synchronize(); ts.append(tr.last_kernel_ms())
-    print("band_count", bc, "rows", tr.rows, "median ms %.3f" % float(np.median(ts[2:])), "-> per full frame %.3f" % (float(np.median(ts[2:])) * bc))
+        ts.append(tr.last_kernel_ms())
+    print("band_count", bc, "rows", tr.rows, "median ms %.3f" % float(np.median(ts[20:])), "-> per full frame %.3f" % (float(np.median(ts[20:])) * bc))

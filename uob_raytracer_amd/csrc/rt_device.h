@@ -71,6 +71,7 @@ struct FrameParams {
   int32_t aa_magic;       // wave kernel: ceil(65536 / aa): lane / aa == (lane * aa_magic) >> 16 for lane < 64
   int32_t aax_magic;      // ceil(65536 / aa_x): a / aa_x == (a * aax_magic) >> 16 for an AA sample index a < 4096
   int32_t job_tasks;      // wave kernel: 64-ray tasks per job (a job = job_tasks * 64 / aa consecutive pixels of a row)
+  int32_t split_listed;   // wave kernel: 1 = last frame's expensive jobs are handed out one task at a time (short frames)
   // wave kernel: jobs that were expensive in the previous frame of this context are handed out first (the kernel
   // ends when its last job does, so the long ones should start early); nullptr = plain order
   const unsigned int* heavy_prev;     // their job ids

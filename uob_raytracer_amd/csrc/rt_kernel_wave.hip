@@ -356,10 +356,18 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
   for (;;) {
   int job = 0;
   const int jt = P.job_tasks;                 // tasks of this hand-out
+  int k0 = 0, k1 = jt;                        // the tasks of the job this hand-out covers
   if (phase_a) {
     if (lane == 0) job = (int)atomicAdd(P.job_counter + (kJobHeads + head) * kJobHeadStride, 1u);
-    const unsigned int unit = (unsigned int)__builtin_amdgcn_readfirstlane(job) * kJobHeads + (unsigned int)head;
-    if (unit >= n_heavy) { phase_a = false; continue; }
+    unsigned int unit = (unsigned int)__builtin_amdgcn_readfirstlane(job) * kJobHeads + (unsigned int)head;
+    if (P.split_listed) {
+      // UOB_RT_SPLIT_LISTED=1: the listed jobs go out one TASK at a time (unit u = task u / n of listed job u % n, all
+      // first tasks before all second ones) — for frames so short that one job's 64 undecided surface points per task
+      // (25x an ordinary task, profiles/r02_wave_timeline.txt) could be the critical path.  Measured: they are not.
+      const unsigned int q = unit / n_heavy;
+      if (q >= (unsigned int)jt) { phase_a = false; continue; }
+      unit -= q * n_heavy; k0 = (int)q; k1 = k0 + 1;
+    } else if (unit >= n_heavy) { phase_a = false; continue; }
     job = (int)P.heavy_prev[unit];
     if (job < 0 || job >= P.njobs) continue;
   } else {
@@ -394,6 +402,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
     }
     if ((listed & 1u) != 0u) continue;                                    // listed: taken care of by phase A
   }
+  k0 = __builtin_amdgcn_readfirstlane(k0); k1 = __builtin_amdgcn_readfirstlane(k1);   // (the same in every lane; see `wave` above)
   RT_STAMP(7)                               // 7: waiting for the hand-out (PROF builds)
   if (timeline && lane == 0) tls[1] += 1ull;
   const unsigned long long job_t0 = lpt ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -432,7 +441,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
                                            1.0001f * bsqrt(dot3(eu, eu)), false)) != 0ull;
   }
   RT_STAMP(0)                               // 0: job set-up (primary-ray bounds of the job)
-  for (int k = 0; k < jt; ++k) {
+  for (int k = k0; k < k1; ++k) {
     const int lnA = opaque(lane);
     // ---- phase 1: 64 primary rays, lnA = (pixel, AA sample) -----------------------------------------
     const int pA = (lnA * P.aa_magic) >> 16;   // lnA / aa
@@ -700,7 +709,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
   }
   // ---- store: the job's consecutive pixels, one coalesced access per wave ------------------------------
   const int x = x0 + lane;
-  if (!COUNT && !PROF && lane < JP && x < P.W) {
+  if (!COUNT && !PROF && lane >= k0 * PT && lane < k1 * PT && x < P.W) {
     const f3 c = mk(div_count(outc.x, aa, P.inv_aa), div_count(outc.y, aa, P.inv_aa), div_count(outc.z, aa, P.inv_aa));
     const size_t o = (size_t)(P.out_global ? y : lr) * P.W + x;
     P.out_argb[o] = pack_argb(c);
@@ -708,8 +717,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
   }
   if (lpt) {
     const unsigned long long cost = __builtin_amdgcn_s_memtime() - job_t0;
-    if (lane == 0) { cost_acc[0] += cost; cost_acc[1] += (unsigned long long)jt; }
-    if (cost > heavy_thr * (unsigned long long)jt && lane == 0) {
+    if (lane == 0) { cost_acc[0] += cost; cost_acc[1] += (unsigned long long)(k1 - k0); }
+    if (cost > heavy_thr * (unsigned long long)(k1 - k0) && lane == 0) {
       // listed once per frame, by whichever wave finds one of its tasks expensive first
       const unsigned int was = atomicMax(P.heavy_flags + job, P.heavy_gen + 1u);
       if (was < P.heavy_gen + 1u) {
