@@ -13,7 +13,8 @@
  * State a context carries from frame to frame: the wave kernel hands out the row segments that were expensive
  * in the context's PREVIOUS frame first (scheduling only — no pixel depends on it; RT_FLAG_PLAIN_ORDER
  * switches it off).  Tuning knobs are read ONCE, in rt_init, from the environment (UOB_RT_JOB_TASKS,
- * UOB_RT_HEAVY_FACTOR4, UOB_RT_FULL_GRID: see DESIGN.md 4.1); nothing reads the environment afterwards.
+ * UOB_RT_HEAVY_FACTOR4, UOB_RT_FULL_GRID, UOB_RT_SPLIT_LISTED, UOB_RT_TIMELINE: see DESIGN.md 4.1); nothing reads the
+ * environment afterwards.
  */
 #ifndef UOB_RT_H
 #define UOB_RT_H
