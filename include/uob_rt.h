@@ -19,6 +19,7 @@
 #ifndef UOB_RT_H
 #define UOB_RT_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -161,6 +162,17 @@ int rt_debug_trace_rays(rt_ctx* ctx, int32_t what, const float* rays6, const flo
  * ceil(owned_rows/16) x ceil(width/16) blocks; writes min(count, cap) values, returns the block count, or
  * RT_E_UNSUPPORTED when the context keeps no such state (n <= 64, RT_FLAG_PLAIN_ORDER, generic kernel).          */
 int rt_debug_block_costs(rt_ctx* ctx, uint32_t* out, int32_t cap);
+
+/* Optional: let the device write the frame STRAIGHT into the caller's host framebuffer (screen->buffer,
+ * SDLauxiliary.h:105) instead of rendering into device memory and copying 4 bytes per pixel back after the kernel
+ * (clEnqueueReadBuffer, skeleton.cpp:179-180): the pixels cross PCIe while the frame is still being rendered.
+ * rt_register_output pins and maps `bytes` bytes at `host` until rt_unregister_output / rt_destroy; every later
+ * rt_render of this context whose out_argb range lies inside a registered range (and whose out_rgb_f32 is NULL) takes
+ * the direct path.  Same pixels, same blocking semantics.  The caller must not free the memory while it is registered.
+ * One range per context; single-device contexts only (a multi-device context delivers its bands with the copy
+ * engines: RT_E_UNSUPPORTED).                                                                                      */
+int rt_register_output(rt_ctx* ctx, void* host, size_t bytes);
+int rt_unregister_output(rt_ctx* ctx);
 
 /* Diagnostic, wave kernel (n <= 64), contexts created with UOB_RT_TIMELINE=1 in the environment: how the persistent
  * waves of the most recent frame spent the kernel's duration, from the 100 MHz s_memrealtime clock.

@@ -77,3 +77,27 @@ def test_wave_timeline_diagnostic(scene, monkeypatch):
         assert t["waves"] > 0 and t["span_us"] > 0 and 0 <= t["mean_idle_tail_us"] <= t["span_us"]
         assert t["jobs"] >= 512 * 256 // 64 and t["max_jobs_per_wave"] >= 1      # every job taken by exactly one wave
     tr.close()
+
+
+def test_registered_output_is_the_same_frame(scene):
+    """rt_register_output: the kernel writes straight into the caller's (pinned, mapped) host framebuffer; same pixels as the
+    device-buffer + copy path, also for a sub-range of the registered memory, and again after unregistering."""
+    cfg = abi.make_config(width=300, height=200, aa_x=2, aa_y=2, shadow_samples=16)
+    rot, cam, light = rt.rotation_matrix(0.2, -0.1), [0.1, 0, -3.0], [0.2, -0.5, -0.7]
+    tr = rt.RayTracer(cfg, scene)
+    ref = tr.render(rot, cam, light, 600.0)
+    big = np.zeros((3, 200, 300), np.uint32)
+    tr.register_output(big)
+    for k in (1, 0, 2):
+        got = tr.render(rot, cam, light, 600.0, out=big[k])
+        assert np.array_equal(got, ref)
+    other = np.zeros((200, 300), np.uint32)                    # not registered: the copy path
+    assert np.array_equal(tr.render(rot, cam, light, 600.0, out=other), ref)
+    tr.unregister_output()
+    big[:] = 0
+    assert np.array_equal(tr.render(rot, cam, light, 600.0, out=big[1]), ref)
+    multi = rt.RayTracer(abi.make_config(width=300, height=200, aa_x=2, aa_y=2, shadow_samples=16, devices=(0, 0)), scene)
+    with pytest.raises(rt.RtError):
+        multi.register_output(big)
+    multi.close()
+    tr.close()

@@ -9,6 +9,7 @@
 //   uob_raytracer [--size N] [--frames K] [--aa X Y] [--shadows S] [--keys "left left i"] [--out file.bmp]
 //                 [--obj mesh.obj]            append load_obj(mesh.obj) to the box, as skeleton.cpp:102-103 does
 //                 [--gpus N | --devices a,b,..]  render every frame on several GPUs inside the one context
+//                 [--copy-back]                  device buffer + blocking read-back instead of rt_register_output
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -84,6 +85,7 @@ bool update() {                                                // :282-361
 }
 
 int main(int argc, char* argv[]) {
+  bool direct_out = true;
   int frames = 10;
   const char* out = "screenshot.bmp";
   const char* obj = nullptr;
@@ -98,6 +100,7 @@ int main(int argc, char* argv[]) {
     else if (a == "--keys" && i + 1 < argc) { istringstream in(argv[++i]); string k; while (in >> k) g_keys.push_back(k); }
     else if (a == "--out" && i + 1 < argc) out = argv[++i];
     else if (a == "--obj" && i + 1 < argc) obj = argv[++i];
+    else if (a == "--copy-back") direct_out = false;           // render into device memory + blocking copy, as the reference reads back
     else if (a == "--gpus" && i + 1 < argc) {
       cfg.num_devices = atoi(argv[++i]);
       if (cfg.num_devices < 1 || cfg.num_devices > RT_MAX_DEVICES) { fprintf(stderr, "--gpus must be in [1,%d]\n", RT_MAX_DEVICES); return 2; }
@@ -124,6 +127,10 @@ int main(int argc, char* argv[]) {
   }
   printf("Triangles Length size %lu\n", triangles.size());                    // :104
   opencl_initialise(cfg);                                                      // :106
+  // the device writes finished pixels straight into screen->buffer (no read-back after the kernel); one GPU only
+  if (direct_out && cfg.num_devices <= 1 &&
+      rt_register_output(g_rt, screen->buffer, (size_t)SCREEN_WIDTH * SCREEN_HEIGHT * sizeof(uint32_t)) != RT_OK)
+    die("rt_register_output");
 
   offload_rendering(screen);                                                   // initial scene, :109-110
   SDL_Renderframe(screen);

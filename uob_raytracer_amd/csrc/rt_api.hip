@@ -99,6 +99,8 @@ struct rt_ctx {
   // wave kernel: last frame's expensive jobs go first (rt_device.h FrameParams::heavy_*); two lists, used in turn
   unsigned int *d_heavy[2] = {nullptr, nullptr}, *d_heavy_flags = nullptr;
   int heavy_cap = 0, heavy_phase = 0;
+  // rt_register_output: a host range the device writes frames into directly
+  char* reg_host = nullptr; char* reg_dev = nullptr; size_t reg_bytes = 0;
   bool timeline_valid = false;   // the last frame left one (start, end, jobs) record per wave in d_timeline
   uint64_t* d_timeline = nullptr;
   size_t timeline_waves = 0;
@@ -729,6 +731,15 @@ int rt_render(rt_ctx* c, const float rot[12], const float cam[3], const float li
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMalloc(&c->d_rgb, (px ? px : 1) * sizeof(float4)));
   }
+  if (c->reg_host && !out_rgb_f32 && px != 0 && (char*)out_argb >= c->reg_host &&
+      (char*)out_argb + px * 4 <= c->reg_host + c->reg_bytes) {
+    // the caller's framebuffer is mapped: the kernel's stores ARE the read-back (rt_register_output)
+    uint32_t* const d_out = reinterpret_cast<uint32_t*>(c->reg_dev + ((char*)out_argb - c->reg_host));
+    const int rc0 = launch_frame(c, rot, cam, light, focal, d_out, nullptr, c->stream);
+    if (rc0 != RT_OK) return rc0;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RT_OK;
+  }
   int rc = launch_frame(c, rot, cam, light, focal, c->d_argb, out_rgb_f32 ? c->d_rgb : nullptr, c->stream);
   if (rc != RT_OK) return rc;
   if (px == 0) return RT_OK;
@@ -736,6 +747,36 @@ int rt_render(rt_ctx* c, const float rot[12], const float cam[3], const float li
   HIP_TRY(hipMemcpyAsync(out_argb, c->d_argb, px * 4, hipMemcpyDeviceToHost, c->stream));
   if (out_rgb_f32) HIP_TRY(hipMemcpyAsync(out_rgb_f32, c->d_rgb, px * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  return RT_OK;
+}
+
+int rt_unregister_output(rt_ctx* c) {
+  if (!c) { set_error("NULL argument"); return RT_E_INVALID; }
+  if (!c->reg_host) return RT_OK;
+  DeviceGuard guard;
+  HIP_TRY(hipSetDevice(c->device));
+  if (c->timed) HIP_TRY(hipEventSynchronize(c->ev1));
+  HIP_TRY(hipHostUnregister(c->reg_host));
+  c->reg_host = c->reg_dev = nullptr; c->reg_bytes = 0;
+  return RT_OK;
+}
+
+int rt_register_output(rt_ctx* c, void* host, size_t bytes) {
+  if (!c || !host || bytes == 0) { set_error("NULL argument"); return RT_E_INVALID; }
+  if (!c->kids.empty()) { set_error("rt_register_output: a multi-device context delivers its bands with the copy engines"); return RT_E_UNSUPPORTED; }
+  const int rc = rt_unregister_output(c);
+  if (rc != RT_OK) return rc;
+  DeviceGuard guard;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipHostRegister(host, bytes, hipHostRegisterMapped | hipHostRegisterPortable));
+  void* dev = nullptr;
+  const hipError_t e = hipHostGetDevicePointer(&dev, host, 0);
+  if (e != hipSuccess || !dev) {
+    hipHostUnregister(host);
+    set_error("hipHostGetDevicePointer failed: %s", hipGetErrorString(e));
+    return RT_E_DEVICE;
+  }
+  c->reg_host = static_cast<char*>(host); c->reg_dev = static_cast<char*>(dev); c->reg_bytes = bytes;
   return RT_OK;
 }
 
@@ -924,6 +965,7 @@ void rt_destroy(rt_ctx* c) {
   hipFree(c->d_verts); hipFree(c->d_normals); hipFree(c->d_colors);
   hipFree(c->d_argb); hipFree(c->d_rgb); hipFree(c->d_counters); hipFree(c->d_records); hipFree(c->d_jobctr);
   hipFree(c->d_screen_masks); hipFree(c->d_world_masks); hipFree(c->d_world_occ);
+  if (c->reg_host) hipHostUnregister(c->reg_host);
   hipFree(c->d_heavy[0]); hipFree(c->d_heavy[1]); hipFree(c->d_heavy_flags); hipFree(c->d_timeline);
   hipFree(c->d_mesh_cost); hipFree(c->d_mesh_order); hipFree(c->d_spheres);
   hipFree(c->d_verts_m); hipFree(c->d_normals_m); hipFree(c->d_colors_m); hipFree(c->d_orig); hipFree(c->d_tile_box);

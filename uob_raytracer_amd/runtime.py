@@ -17,7 +17,7 @@ EXPORTS = (
     "rt_abi_version", "rt_last_error", "rt_config_default", "rt_config_owned_rows", "rt_init", "rt_render",
     "rt_render_device", "rt_count_work", "rt_count_executed", "rt_last_kernel_ms", "rt_destroy", "rt_scene_cornell_box",
     "rt_scene_load_obj", "rt_scene_load_obj_ex", "rt_triangle_compute_normal", "rt_scene_pack", "rt_rotation_matrix",
-    "rt_selftest_rcp", "rt_debug_trace_rays", "rt_debug_block_costs", "rt_debug_wave_timeline",
+    "rt_selftest_rcp", "rt_debug_trace_rays", "rt_debug_block_costs", "rt_debug_wave_timeline", "rt_register_output", "rt_unregister_output",
 )
 
 _lib = None
@@ -56,6 +56,8 @@ def lib():
         L.rt_debug_trace_rays.argtypes = [vp, C.c_int32, fp, fp, C.c_int64, C.POINTER(C.c_int32), fp]
         L.rt_debug_block_costs.argtypes = [vp, C.POINTER(C.c_uint32), C.c_int32]
         L.rt_debug_wave_timeline.argtypes = [vp, C.POINTER(C.c_uint64)]
+        L.rt_register_output.argtypes = [vp, vp, C.c_size_t]
+        L.rt_unregister_output.argtypes = [vp]
         L.rt_triangle_compute_normal.argtypes = [C.POINTER(abi.RtTriangle)]
         L.rt_triangle_compute_normal.restype = None
         L.rt_scene_pack.argtypes = [C.POINTER(abi.RtTriangle), C.c_int32, fp, fp, fp]
@@ -187,6 +189,16 @@ class RayTracer:
         _check(lib().rt_render(self._h, _fp(rot), _fp(cam), _fp(light), C.c_float(focal),
                                argb.ctypes.data_as(C.POINTER(C.c_uint32)), _fp(rgb) if want_rgb else None))
         return (argb, rgb) if want_rgb else argb
+
+    def register_output(self, arr):
+        """Pin and map a host array (the caller's framebuffer): later render(out=arr) calls have the kernel write the pixels
+        straight into it over PCIe (rt_register_output).  Keep `arr` alive until unregister_output() / close()."""
+        _check(lib().rt_register_output(self._h, C.c_void_p(arr.ctypes.data), C.c_size_t(arr.nbytes)))
+        self._registered = arr
+
+    def unregister_output(self):
+        _check(lib().rt_unregister_output(self._h))
+        self._registered = None
 
     def render_device(self, rot, cam, light, focal, d_argb_ptr, d_rgb_ptr=None, stream=None):
         """Enqueue a frame into caller-owned device memory (raw pointers, e.g. torch .data_ptr())."""
