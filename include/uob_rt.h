@@ -169,8 +169,8 @@ int rt_debug_block_costs(rt_ctx* ctx, uint32_t* out, int32_t cap);
  * rt_register_output pins and maps `bytes` bytes at `host` until rt_unregister_output / rt_destroy; every later
  * rt_render of this context whose out_argb range lies inside a registered range (and whose out_rgb_f32 is NULL) takes
  * the direct path.  Same pixels, same blocking semantics.  The caller must not free the memory while it is registered.
- * One range per context; single-device contexts only (a multi-device context delivers its bands with the copy
- * engines: RT_E_UNSUPPORTED).                                                                                      */
+ * One range per context.  In a multi-device context every device writes its bands into the range over its own PCIe
+ * link (RT_FLAG_STAGED_GATHER keeps the copy engines).                                                             */
 int rt_register_output(rt_ctx* ctx, void* host, size_t bytes);
 int rt_unregister_output(rt_ctx* ctx);
 

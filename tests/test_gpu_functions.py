@@ -96,8 +96,20 @@ def test_registered_output_is_the_same_frame(scene):
     tr.unregister_output()
     big[:] = 0
     assert np.array_equal(tr.render(rot, cam, light, 600.0, out=big[1]), ref)
-    multi = rt.RayTracer(abi.make_config(width=300, height=200, aa_x=2, aa_y=2, shadow_samples=16, devices=(0, 0)), scene)
-    with pytest.raises(rt.RtError):
-        multi.register_output(big)
-    multi.close()
     tr.close()
+    # several device entries: each writes its own bands into the registered frame
+    for devs, h in (((0, 0), 200), ((0, 0, 0), 173)):
+        cfgm = abi.make_config(width=300, height=h, aa_x=2, aa_y=2, shadow_samples=16, devices=devs, device_band_rows=16)
+        one = rt.RayTracer(abi.make_config(width=300, height=h, aa_x=2, aa_y=2, shadow_samples=16), scene)
+        want = one.render(rot, cam, light, 600.0)
+        one.close()
+        multi = rt.RayTracer(cfgm, scene)
+        frame = np.zeros((h, 300), np.uint32)
+        multi.register_output(frame)
+        for _ in range(2):
+            frame[:] = 0
+            assert np.array_equal(multi.render(rot, cam, light, 600.0, out=frame), want)
+        multi.unregister_output()
+        frame[:] = 0
+        assert np.array_equal(multi.render(rot, cam, light, 600.0, out=frame), want)
+        multi.close()

@@ -8,3 +8,5 @@ run --size 1024 --frames 200 --copy-back
 run --size 4096 --aa 4 2 --shadows 64 --frames 100 --copy-back
 run --size 4096 --aa 4 2 --shadows 64 --frames 100 --devices 0,0
 run --size 4096 --aa 4 2 --shadows 64 --frames 100 --devices 0,0,0,0
+run --size 4096 --aa 4 2 --shadows 64 --frames 100 --devices 0,0 --copy-back
+run --size 4096 --aa 4 2 --shadows 64 --frames 100 --devices 0,0,0,0 --copy-back

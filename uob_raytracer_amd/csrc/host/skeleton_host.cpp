@@ -127,8 +127,8 @@ int main(int argc, char* argv[]) {
   }
   printf("Triangles Length size %lu\n", triangles.size());                    // :104
   opencl_initialise(cfg);                                                      // :106
-  // the device writes finished pixels straight into screen->buffer (no read-back after the kernel); one GPU only
-  if (direct_out && cfg.num_devices <= 1 &&
+  // the device(s) write finished pixels straight into screen->buffer (no read-back after the kernel)
+  if (direct_out &&
       rt_register_output(g_rt, screen->buffer, (size_t)SCREEN_WIDTH * SCREEN_HEIGHT * sizeof(uint32_t)) != RT_OK)
     die("rt_register_output");
 

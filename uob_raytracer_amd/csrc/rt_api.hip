@@ -101,6 +101,7 @@ struct rt_ctx {
   int heavy_cap = 0, heavy_phase = 0;
   // rt_register_output: a host range the device writes frames into directly
   char* reg_host = nullptr; char* reg_dev = nullptr; size_t reg_bytes = 0;
+  bool reg_owner = false;        // this context called hipHostRegister (a child of a multi-device context only holds its device's alias)
   bool timeline_valid = false;   // the last frame left one (start, end, jobs) record per wave in d_timeline
   uint64_t* d_timeline = nullptr;
   size_t timeline_waves = 0;
@@ -680,9 +681,14 @@ static int parent_render(rt_ctx* p, const float rot[12], const float cam[3], con
     const bool want_rgb = to_host ? host_rgb != nullptr : d_rgb != nullptr;
     if (want_rgb && !c->d_rgb) HIP_TRY(hipMalloc(&c->d_rgb, (size_t)c->owned_rows * W * sizeof(float4)));
     if (!to_host) HIP_TRY(hipStreamWaitEvent(c->stream, p->ev_go, 0));
-    // a device that holds the destination writes its rows there itself; the others render into their stripe
-    const bool direct = !to_host && c->device == p->device && !(p->cfg.flags & RT_FLAG_STAGED_GATHER);
-    int rc = direct ? launch_frame(c, rot, cam, light, focal, d_argb, d_rgb, c->stream, true)
+    // a device that holds the destination writes its rows there itself; the others render into their stripe.  A registered
+    // host framebuffer (rt_register_output) is held by every device: each writes its bands into it over its own PCIe link.
+    const bool mapped = to_host && !host_rgb && c->reg_host && (char*)host_argb >= c->reg_host &&
+                        (char*)host_argb + (size_t)p->cfg.height * W * 4 <= c->reg_host + c->reg_bytes &&
+                        !(p->cfg.flags & RT_FLAG_STAGED_GATHER);
+    const bool direct = mapped || (!to_host && c->device == p->device && !(p->cfg.flags & RT_FLAG_STAGED_GATHER));
+    uint32_t* const dst = mapped ? reinterpret_cast<uint32_t*>(c->reg_dev + ((char*)host_argb - c->reg_host)) : d_argb;
+    int rc = direct ? launch_frame(c, rot, cam, light, focal, dst, mapped ? nullptr : d_rgb, c->stream, true)
                     : launch_frame(c, rot, cam, light, focal, c->d_argb, want_rgb ? c->d_rgb : nullptr, c->stream);
     if (rc != RT_OK) return rc;
     if (!direct) {
@@ -752,31 +758,43 @@ int rt_render(rt_ctx* c, const float rot[12], const float cam[3], const float li
 
 int rt_unregister_output(rt_ctx* c) {
   if (!c) { set_error("NULL argument"); return RT_E_INVALID; }
-  if (!c->reg_host) return RT_OK;
+  if (!c->reg_host || !c->reg_owner) return RT_OK;
   DeviceGuard guard;
+  for (rt_ctx* k : c->kids) {                        // no frame of any device may still be writing
+    HIP_TRY(hipSetDevice(k->device));
+    HIP_TRY(hipStreamSynchronize(k->stream));
+    k->reg_host = k->reg_dev = nullptr; k->reg_bytes = 0;
+  }
   HIP_TRY(hipSetDevice(c->device));
   if (c->timed) HIP_TRY(hipEventSynchronize(c->ev1));
   HIP_TRY(hipHostUnregister(c->reg_host));
-  c->reg_host = c->reg_dev = nullptr; c->reg_bytes = 0;
+  c->reg_host = c->reg_dev = nullptr; c->reg_bytes = 0; c->reg_owner = false;
   return RT_OK;
 }
 
 int rt_register_output(rt_ctx* c, void* host, size_t bytes) {
   if (!c || !host || bytes == 0) { set_error("NULL argument"); return RT_E_INVALID; }
-  if (!c->kids.empty()) { set_error("rt_register_output: a multi-device context delivers its bands with the copy engines"); return RT_E_UNSUPPORTED; }
   const int rc = rt_unregister_output(c);
   if (rc != RT_OK) return rc;
   DeviceGuard guard;
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipHostRegister(host, bytes, hipHostRegisterMapped | hipHostRegisterPortable));
-  void* dev = nullptr;
-  const hipError_t e = hipHostGetDevicePointer(&dev, host, 0);
-  if (e != hipSuccess || !dev) {
+  auto alias = [&](rt_ctx* x) -> bool {              // the range as device x->device addresses it
+    void* dev = nullptr;
+    if (hipSetDevice(x->device) != hipSuccess || hipHostGetDevicePointer(&dev, host, 0) != hipSuccess || !dev) return false;
+    x->reg_host = static_cast<char*>(host); x->reg_dev = static_cast<char*>(dev); x->reg_bytes = bytes;
+    return true;
+  };
+  bool ok = alias(c);
+  for (rt_ctx* k : c->kids) ok = ok && alias(k);
+  if (!ok) {
+    for (rt_ctx* k : c->kids) { k->reg_host = k->reg_dev = nullptr; k->reg_bytes = 0; }
+    c->reg_host = c->reg_dev = nullptr; c->reg_bytes = 0;
     hipHostUnregister(host);
-    set_error("hipHostGetDevicePointer failed: %s", hipGetErrorString(e));
+    set_error("hipHostGetDevicePointer failed: %s", hipGetErrorString(hipGetLastError()));
     return RT_E_DEVICE;
   }
-  c->reg_host = static_cast<char*>(host); c->reg_dev = static_cast<char*>(dev); c->reg_bytes = bytes;
+  c->reg_owner = true;
   return RT_OK;
 }
 
@@ -965,7 +983,7 @@ void rt_destroy(rt_ctx* c) {
   hipFree(c->d_verts); hipFree(c->d_normals); hipFree(c->d_colors);
   hipFree(c->d_argb); hipFree(c->d_rgb); hipFree(c->d_counters); hipFree(c->d_records); hipFree(c->d_jobctr);
   hipFree(c->d_screen_masks); hipFree(c->d_world_masks); hipFree(c->d_world_occ);
-  if (c->reg_host) hipHostUnregister(c->reg_host);
+  if (c->reg_host && c->reg_owner) hipHostUnregister(c->reg_host);
   hipFree(c->d_heavy[0]); hipFree(c->d_heavy[1]); hipFree(c->d_heavy_flags); hipFree(c->d_timeline);
   hipFree(c->d_mesh_cost); hipFree(c->d_mesh_order); hipFree(c->d_spheres);
   hipFree(c->d_verts_m); hipFree(c->d_normals_m); hipFree(c->d_colors_m); hipFree(c->d_orig); hipFree(c->d_tile_box);
