@@ -1045,6 +1045,22 @@ __global__ __launch_bounds__(1024) void rt_mesh_order(const unsigned int* cost, 
   }
 }
 
+// First frame of a context (no costs yet): a block's cost is guessed as the number of candidate tiles of its screen cell —
+// the blocks on the mesh's silhouette are the expensive ones — so that the first frame, too, starts its long blocks first
+// (and splits the dearest four ways) instead of meeting them in row order.  Scheduling only.
+__global__ void rt_mesh_estimate(const FrameParams P, unsigned int* cost, int n_jobs) {
+  const int job = blockIdx.x * blockDim.x + threadIdx.x;
+  if (job >= n_jobs) return;
+  const int wgx_n = (P.W + 15) / 16, wg_rows = (P.owned_rows + 15) / 16, wg_mid = (wg_rows + 1) >> 1;
+  const int job_y = job / wgx_n, job_x = job - job_y * wgx_n;
+  const int wg_row = (job_y & 1) ? wg_mid + (job_y >> 1) : wg_mid - 1 - (job_y >> 1);
+  const int lrr = wg_row * 16 < P.owned_rows ? wg_row * 16 : P.owned_rows - 1;
+  const int cx = (job_x * 16) >> kScreenCellLog, cy = band_global_row(P, lrr) >> kScreenCellLog;
+  unsigned int c = 1u;
+  for (int w = 0; w < P.nwords; ++w) c += (unsigned int)__popcll(P.screen_masks[((size_t)cy * P.scx + cx) * P.nwords + w]);
+  cost[job] = c;
+}
+
 bool mesh_kernel_supports(const FrameParams& P) {
   const int aa = P.aa_x * P.aa_y;
   return P.records != nullptr && P.S >= 1 && P.S <= 4096 && aa >= 1 && aa <= 64 && P.n > 64 && P.spread >= 0.0f;
@@ -1078,10 +1094,17 @@ void launch_mesh(const FrameParams& P, bool count, bool prof, hipStream_t stream
   hipMemsetAsync(P.job_counter, 0, sizeof(unsigned int), stream);
   const size_t lds_bytes = kBatch * kSlot * sizeof(float4) + kMeshWaves * (size_t)mesh_wave_lds_bytes(P.S > kPointSamples || P.nsph > 0) + 2 * (size_t)nwords * 8 +
                            kMeshWaves * 64 * (20 + 8 + 4);          // + the cooperative blocks' merge area
+  FrameParams Q = P;
+  if (!count && P.mesh_order == nullptr && P.mesh_cost != nullptr && P.mesh_order_out != nullptr && P.screen_masks != nullptr &&
+      !(P.mask_debug & 16)) {                           // the context's first frame: order it by the guess (mask_debug 16: do not)
+    hipLaunchKernelGGL(rt_mesh_estimate, dim3((n_jobs + 255) / 256), dim3(256), 0, stream, P, P.mesh_cost, n_jobs);
+    hipLaunchKernelGGL(rt_mesh_order, dim3(1), dim3(1024), 0, stream, P.mesh_cost, P.mesh_order_out, P.mesh_queue_len, n_jobs, (P.mask_debug & 8) ? 1 : 0);
+    Q.mesh_order = P.mesh_order_out;
+  }
   if (!count && P.mesh_cost != nullptr) hipMemsetAsync(P.mesh_cost, 0, (size_t)n_jobs * 4, stream);
-  if (count && prof) hipLaunchKernelGGL((rt_draw_mesh<false, true>), grid, block, lds_bytes, stream, P);
-  else if (count) hipLaunchKernelGGL((rt_draw_mesh<true>), grid, block, lds_bytes, stream, P);
-  else hipLaunchKernelGGL((rt_draw_mesh<false>), grid, block, lds_bytes, stream, P);
+  if (count && prof) hipLaunchKernelGGL((rt_draw_mesh<false, true>), grid, block, lds_bytes, stream, Q);
+  else if (count) hipLaunchKernelGGL((rt_draw_mesh<true>), grid, block, lds_bytes, stream, Q);
+  else hipLaunchKernelGGL((rt_draw_mesh<false>), grid, block, lds_bytes, stream, Q);
   if (!count && P.mesh_cost != nullptr && P.mesh_order_out != nullptr)
     hipLaunchKernelGGL(rt_mesh_order, dim3(1), dim3(1024), 0, stream, P.mesh_cost, P.mesh_order_out, P.mesh_queue_len, n_jobs, (P.mask_debug & 8) ? 1 : 0);
 }
