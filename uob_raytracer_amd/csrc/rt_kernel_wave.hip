@@ -47,6 +47,8 @@
 #define RT_CHUNK 4          // jobs per hand-out while the queue is long (2: 3.58 ms, 4: 3.50, 8: 3.64 on the headline frame)
 #endif
 
+#include <type_traits>
+
 namespace uobrt {
 
 namespace {
@@ -521,7 +523,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
     // ---- phase 3: shadows of the lit surface points ---------------------------------------------------
     int unshadowed = NS;                        // samples of this lnB's surface point that reach the light
     unsigned long long work = ballot(lit);      // lanes whose samples must really be tested (level 3)
-    unsigned long long K = tri_lanes, need = ~0ull, sphmask = P.nsph > 0 ? ~0ull : 0ull;
+    // need: per surface point, the casters (as positions among K's set bits) whose samples must be tested; with at most 32
+    // casters (the static-layout build) it is one register, and one lane read per point in level 3
+    using need_t = typename std::conditional<STRIDE == 32, uint32_t, unsigned long long>::type;
+    unsigned long long K = tri_lanes, sphmask = P.nsph > 0 ? ~0ull : 0ull;
+    need_t need = (need_t)~(need_t)0;
     if (CULL && work != 0ull) {
       // bounds used by the cull (never by the shading): |dir|, jitter half-width with rounding slack
       const float dlen = bsqrt(radius_sq);
@@ -572,7 +578,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
         // level 2: per surface point, lnB = point, over the triangles K that survived level 1
 
         bool blocked = sph_blocked;
-        need = 0ull;
+        need = (need_t)0;
         int pos = 0;
         for (unsigned long long kk = K; kk != 0ull; kk &= kk - 1ull, ++pos) {
           const int kq = __builtin_ctzll(kk);
@@ -585,12 +591,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
           }
           const Bound pb = point_bound(start, dir, hh, dlen, dminlen, dk, xyz(SC.v0[kq]), xyz(SC.e1[kq]), xyz(SC.e2[kq]),
                                        xyz(SC.c[kq]));
-          if (!pb.clear || !sane) need |= 1ull << pos;
+          if (!pb.clear || !sane) need |= (need_t)((need_t)1 << pos);
           blocked = blocked || (sane && pb.all_blocked);
         }
         if (blocked) unshadowed = 0;
-        work = ballot(lit && !blocked && (need != 0ull || ((sphmask >> lnB) & 1ull) != 0ull));
-        if (COUNT) { xw.v[4] += (unsigned)__popcll(ballot(lit && !blocked && need == 0ull)); if (work == 0ull) xw.v[5] += 1; }
+        work = ballot(lit && !blocked && (need != (need_t)0 || ((sphmask >> lnB) & 1ull) != 0ull));
+        if (COUNT) { xw.v[4] += (unsigned)__popcll(ballot(lit && !blocked && need == (need_t)0)); if (work == 0ull) xw.v[5] += 1; }
       }
     }
 
@@ -647,10 +653,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
           if (CULL) {
             const int j2 = pm != 0ull ? base + __builtin_ctzll(pm) : j;   // second point of the pair (or j again)
             pm &= pm - 1ull;                                             // 0 & anything stays 0
-            const unsigned long long n1 = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(need >> 32), j) << 32) |
-                                          (unsigned)__builtin_amdgcn_readlane((int)need, j);
-            const unsigned long long n2 = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(need >> 32), j2) << 32) |
-                                          (unsigned)__builtin_amdgcn_readlane((int)need, j2);
+            unsigned long long n1, n2;
+            if (STRIDE == 32) {
+              n1 = (unsigned)__builtin_amdgcn_readlane((int)(uint32_t)need, j);
+              n2 = (unsigned)__builtin_amdgcn_readlane((int)(uint32_t)need, j2);
+            } else {
+              const unsigned long long nd64 = (unsigned long long)need;
+              n1 = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(nd64 >> 32), j) << 32) | (unsigned)__builtin_amdgcn_readlane((int)nd64, j);
+              n2 = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(nd64 >> 32), j2) << 32) | (unsigned)__builtin_amdgcn_readlane((int)nd64, j2);
+            }
             const Count2 c2 = wave_unshadowed_pair<COUNT>(P, SC, L, lnC, j, j2, K, n1 | n2, (sphmask >> j) & 1ull,
                                                           (sphmask >> j2) & 1ull, jit, act, xw);
             const int before = (MULTI && pass > 0) ? unshadowed : 0;     // j2 may be j again: add once
