@@ -113,3 +113,20 @@ def test_registered_output_is_the_same_frame(scene):
         frame[:] = 0
         assert np.array_equal(multi.render(rot, cam, light, 600.0, out=frame), want)
         multi.close()
+
+
+def test_listed_jobs_task_by_task_is_the_same_frame(scene, monkeypatch):
+    """UOB_RT_SPLIT_LISTED=1 (read once in rt_init): last frame's expensive jobs are handed out one task at a time; pixels
+    do not depend on it — three frames of one context (the list exists from the second on), whole frame and a band rank."""
+    rot, cam, light = rt.rotation_matrix(-0.1, 0.05), [0, 0, -3.2], [0.1, -0.5, -0.7]
+    for extra in ({}, {"band_rows": 32, "band_index": 1, "band_count": 3}):
+        cfg = abi.make_config(width=1024, height=768, aa_x=4, aa_y=2, shadow_samples=64, **extra)
+        plain = rt.RayTracer(cfg, scene)
+        ref = plain.render(rot, cam, light, 4400.0)
+        plain.close()
+        monkeypatch.setenv("UOB_RT_SPLIT_LISTED", "1")
+        tr = rt.RayTracer(cfg, scene)
+        monkeypatch.delenv("UOB_RT_SPLIT_LISTED")
+        for _ in range(3):
+            assert np.array_equal(tr.render(rot, cam, light, 4400.0), ref)
+        tr.close()
