@@ -9,7 +9,10 @@ namespace uobrt {
 
 // The wave kernel's job queue has several heads (a returning device-scope atomic on ONE word saturates at ~88
 // hand-outs per microsecond on this part): head h hands out the jobs h, h + kJobHeads, h + 2 kJobHeads, ...
-constexpr int kJobHeads = 32;
+// An ODD number: a row has a power-of-two number of jobs (64 at 4096 pixels), and with 32 heads every head served the same
+// two columns of the frame for ever — the heads over the penumbra columns ran dry long after the others, whose waves then
+// walked from head to head.  Headline frame: 32 heads 3.08 ms, 8 / 16: 3.04, 12 / 24: 3.00, any odd count 21..31: 2.99; 64: 3.24.
+constexpr int kJobHeads = 31;
 constexpr int kJobHeadStride = 32;      // in 32-bit words: one 128-byte line per head
 // HeavyState, in 32-bit words: [0] entries in the list, [2..3] sum of all job costs (64-bit, s_memtime ticks),
 // [4] jobs counted
