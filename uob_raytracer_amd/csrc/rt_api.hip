@@ -407,7 +407,7 @@ int rt_init(const rt_config* cfg, const float* vertices4, const float* normals4,
     const int aa = cfg->aa_x * cfg->aa_y;
     const int pt = (aa >= 1 && aa <= 64) ? 64 / aa : 64;
     const size_t jobs_max = (size_t)((cfg->width + pt - 1) / pt) * (size_t)(c->owned_rows > 0 ? c->owned_rows : 1);
-    c->heavy_cap = (int)(jobs_max / 8 > 64 ? jobs_max / 8 : 64);
+    c->heavy_cap = (int)(jobs_max / 3 > 64 ? jobs_max / 3 : 64);
     if (hipMemset(c->d_jobctr, 0, (2 * kJobHeads + 2) * kJobHeadStride * sizeof(unsigned int)) != hipSuccess) {
       set_error("hipMemset failed: %s", hipGetErrorString(hipGetLastError())); return fail(RT_E_DEVICE);
     }
@@ -595,7 +595,7 @@ static int launch_frame(rt_ctx* c, const float rot[12], const float cam[3], cons
       P.heavy_new = c->d_heavy[cur]; P.heavy_new_state = st[cur];
       P.heavy_flags = c->d_heavy_flags; P.heavy_gen = ++c->heavy_gen;
       P.heavy_factor4 = c->tune.heavy_factor4;                      // expensive = more than twice the average job
-      P.heavy_cap = P.njobs / 8 < c->heavy_cap ? P.njobs / 8 : c->heavy_cap;
+      P.heavy_cap = P.njobs / 3 < c->heavy_cap ? P.njobs / 3 : c->heavy_cap;
       c->heavy_phase = cur;
     }
     c->timeline_valid = false;
