@@ -349,9 +349,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
   unsigned long long* const tls = reinterpret_cast<unsigned long long*>(L.rng + kRngStride + 256);
   if (timeline && lane == 0) { tls[0] = __builtin_amdgcn_s_memrealtime(); tls[1] = 0ull; }
   bool phase_a = n_heavy != 0u;
-  // Several jobs per hand-out while the queue is long (a hand-out is a returning device-scope atomic that stalls its
-  // wave for microseconds), fewer as it runs out, single jobs over the last stretch, where balance matters more.
-  const int per_wave = 8 * (int)gridDim.x * kWavesPerBlock;
+  // Several jobs per hand-out (a hand-out is a returning device-scope atomic that stalls its wave for microseconds), fewer
+  // as the queue runs out: RT_CHUNK while more than 2 T jobs per wave remain, two while more than T, then one, with T = 8 for
+  // 64-pixel jobs and T = 1 for the halved jobs of short frames, which hold ~16 jobs per wave in all and would otherwise
+  // never see a full hand-out (measured, ms: 1024 rows, 64-pixel jobs: 0.92 with T = 8, 1.00 with T = 1; 512 rows, 32-pixel
+  // jobs: 0.570 against 0.540).
+  const int grid_waves = (int)gridDim.x * kWavesPerBlock;
+  const int per_wave = P.job_tasks * PT > 32 ? 8 * grid_waves : grid_waves;
   int next_job = -1, chunk_left = 0;                    // the rest of the last hand-out, still to do
   unsigned int listed = 0u;                             // bit i: job i of the rest of the hand-out is on last frame's list
   int chunk = P.njobs > 2 * per_wave ? RT_CHUNK : (P.njobs > per_wave ? 2 : 1);      // size of the next hand-out
@@ -386,8 +390,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
         const int jl = job + lane * kJobHeads;
         listed = (unsigned int)ballot(lane <= chunk_left && jl < P.njobs && P.heavy_flags[jl] >= P.heavy_gen);
       }
-      // what this head has left decides the next hand-out: RT_CHUNK jobs while more than ~16 per wave remain in all,
-      // two while more than ~8, then one
+      // what this head has left decides the next hand-out
       const int left = P.njobs - next_job;
       chunk = left > 2 * per_wave ? RT_CHUNK : (left > per_wave ? 2 : 1);
     }
