@@ -87,6 +87,40 @@ def build_variant(name):
     return so
 
 
+# ---- the same kernel text for the GPU itself ----------------------------------------------------------------------
+# clang -x cl for amdgcn-amd-amdhsa links AMD's OpenCL builtin library (opencl.bc / ocml.bc / ockl.bc from the ROCm
+# installation) by itself: every builtin the kernel calls is the one a clBuildProgram on this GPU would use, and the
+# options are the reference's own (skeleton.cpp:407).  Nothing of ours is linked in: this IS the reference built here,
+# for the OpenCL device of the GPU box.  oracle/ref_cl_host.c (our stand-in for the SDL-bound host) loads the code object
+# with clCreateProgramWithBinary and runs it; oracle/ref_gpu.py drives that.
+GPU_ARCH = "gfx950"
+GPU_FAST = ["-O3", "-cl-fast-relaxed-math", "-cl-mad-enable"]      # -O3: the OpenCL runtime's default level
+GPU_PLAIN = ["-O3"]                                                 # no build options at all (OpenCL defaults)
+GPU_VARIANTS = {
+    # name -> (constants of VARIANTS[...], flags)
+    "default":    ("default", GPU_FAST),        # the reference exactly as it builds and runs itself
+    "default_plain": ("default", GPU_PLAIN),
+    "default256": ("default256", GPU_FAST),
+    "cfg1":       ("cfg1", GPU_FAST),
+    "cfg2":       ("cfg2", GPU_FAST),
+    "cfg3":       ("cfg3", GPU_FAST),           # 1920 x 1080: width is a multiple of 128, height of 4
+    "s64_512":    ("s64_512", GPU_FAST),
+    "s64_4096":   ("s64_4096", GPU_FAST),
+    "aa3_256":    ("aa3_256", GPU_FAST),
+}
+
+
+def build_gpu_variant(name):
+    base, flags = GPU_VARIANTS[name]
+    os.makedirs(OUT, exist_ok=True)
+    co = os.path.join(OUT, "ref_%s_%s.co" % (name, GPU_ARCH))
+    src = patched_source(VARIANTS[base])
+    subprocess.run([CLANG, "-x", "cl", "-cl-std=CL1.2", "-target", "amdgcn-amd-amdhsa", "-mcpu=" + GPU_ARCH, *flags,
+                    "-Wno-incompatible-pointer-types", "-Wno-excess-initializers", "-", "-o", co],
+                   input=src.encode(), check=True)
+    return co
+
+
 def build_scene():
     os.makedirs(OUT, exist_ok=True)
     so = os.path.join(OUT, "libref_scene.so")
@@ -103,7 +137,13 @@ def main(argv):
     names = argv or list(VARIANTS)
     build_scene()
     for n in names:
-        print("built", build_variant(n))
+        if n.startswith("gpu:"):
+            print("built", build_gpu_variant(n[4:]))
+        else:
+            print("built", build_variant(n))
+    if not argv:
+        for n in GPU_VARIANTS:
+            print("built", build_gpu_variant(n))
     return 0
 
 
