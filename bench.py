@@ -33,7 +33,7 @@ PEAK_FP32_VALU_TFLOPS = 157.3     # MI355X_MICROARCH.md, chip-level parameters: 
 PEAK_HBM_GBPS = 8000.0
 SIMDS, CLOCK_GHZ = 1024, 2.4       # 256 CUs x 4 SIMD-32; max clock
 VALU_ISSUE_CYCLES = 2             # a wave64 VALU instruction occupies its SIMD-32 for 2 cycles (MI355X_MICROARCH.md)
-PMC_FILE = "r02_pmc.json"         # profiles/: counters per launch from the rocprofv3 --pmc passes of this command
+PMC_FILE = "r03_pmc.json"         # profiles/: counters per launch from the rocprofv3 --pmc passes of this command
 FLOP_PER_TRI_TEST = 46            # Moeller-Trumbore with e1,e2 precomputed
 FLOP_PER_SPHERE_TEST = 30
 
@@ -49,6 +49,20 @@ WORKLOADS = {
     # the reference exactly as shipped
     "reference": dict(width=1024, height=1024),
 }
+
+
+def source_hash():
+    """sha256 over the kernel sources the library is built from (tools/pmc_to_json.py stores the same hash with the
+    counters it collects: counters of another build are flagged stale instead of being priced with this build's time)."""
+    import hashlib
+    d = os.path.join(ROOT, "uob_raytracer_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            h.update(name.encode())
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def build_scene(workload, rt):
@@ -83,6 +97,10 @@ def main():
     ap.add_argument("--force-collective", action="store_true",
                     help="with one rank, still initialise the process group and run the band gather (exercises the "
                          "RCCL calls of the N>1 flow on a one-GPU box)")
+    ap.add_argument("--emulate-rank", default=None, metavar="r/N",
+                    help="ONE process renders rank r's bands of an N-rank split of the frame and goes through the whole N > 1 step "
+                         "(two contexts on two streams, RCCL gather, the root's de-interleave over N stripes): what one rank of the "
+                         "N-GPU job costs per step on the GPU and on the host (enqueue time), measured on a one-GPU box")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 flow on a box with fewer GPUs than ranks (bands travel via host memory)")
     args = ap.parse_args()
@@ -102,8 +120,21 @@ def main():
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    emu = None
+    if args.emulate_rank:
+        er, en = (int(x) for x in args.emulate_rank.split("/"))
+        if world != 1 or not (0 <= er < en <= 64):
+            sys.exit("--emulate-rank r/N needs one process and 0 <= r < N")
+        emu = (er, en)
+        args.force_collective = True
     collective = world > 1 or args.force_collective
+    part_world, part_rank = (emu[1], emu[0]) if emu else (world, rank)     # the band partition this process renders a part of
+    saved_stdout = None
     if collective:
+        # RCCL prints a version banner on stdout when its first communicator is made: keep stdout for the ONE JSON line
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
@@ -116,7 +147,7 @@ def main():
     wl = WORKLOADS[args.workload]
     W, H = wl["width"], wl["height"]
     band_rows = args.band_rows if collective else H
-    cfg = abi.make_config(band_rows=band_rows, band_index=rank, band_count=world, device=local_rank, **wl)
+    cfg = abi.make_config(band_rows=band_rows, band_index=part_rank, band_count=part_world, device=local_rank, **wl)
     scene = build_scene(args.workload, rt)
     tracer = rt.RayTracer(cfg, scene)
     rows = tracer.rows
@@ -125,12 +156,12 @@ def main():
     cam, light = [0.0, 0.0, -3.2], [0.0, -0.5, -0.7]
 
     # every rank sends an equal-size stripe of whole bands (its own rows packed at the top): any height works
-    prow = bands.padded_rows(H, world, band_rows) if collective else rows
+    prow = bands.padded_rows(H, part_world, band_rows) if collective else rows
     stripe = torch.zeros((prow, W), dtype=torch.int32, device=dev)
     gathered = frame_pad = frame = None
     if collective and rank == 0:    # one [world, prow, W] receive buffer; the gather list is its slices
-        gathered = torch.empty((world, prow, W), dtype=torch.int32, device=dev)
-        frame_pad = torch.empty((prow * world, W), dtype=torch.int32, device=dev)
+        gathered = torch.zeros((part_world, prow, W), dtype=torch.int32, device=dev)
+        frame_pad = torch.empty((prow * part_world, W), dtype=torch.int32, device=dev)
         frame = frame_pad[:H]
 
     # N > 1 over RCCL: the render of frame k+1 runs on its own stream into the other of two stripe buffers while
@@ -162,7 +193,7 @@ def main():
                 ev[1].record(render_stream)
             rendered[i].record(render_stream)
             cur.wait_event(rendered[i])
-            bands.gather_frame(stripes[i], world, rank, band_rows, gathered, frame_pad, force=True, height=H)
+            bands.gather_frame(stripes[i], part_world, part_rank, band_rows, gathered, frame_pad, force=True, height=H, emulate=emu is not None)
             consumed[i] = torch.cuda.Event()
             consumed[i].record(cur)
             return
@@ -174,7 +205,7 @@ def main():
             ev[1].record()
         # gloo rehearsal of N > 1: the bands travel via host memory; N == 1: the stripe IS the frame
         if args.backend == "gloo" and collective:
-            host = bands.gather_frame(stripe.cpu(), world, rank, band_rows, force=True, height=H)
+            host = bands.gather_frame(stripe.cpu(), part_world, part_rank, band_rows, force=True, height=H, emulate=emu is not None)
             if rank == 0:
                 frame.copy_(host)
 
@@ -211,6 +242,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(ev[k])
+    host_enqueue_s = time.perf_counter() - t0      # the host's share: every step enqueued, nothing waited for yet
     sync()
     elapsed = time.perf_counter() - t0
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
@@ -246,49 +278,57 @@ def main():
     flops = (total_work["closest_tri_tests"] + total_work["shadow_tri_tests"]) * FLOP_PER_TRI_TEST + \
             (total_work["closest_sphere_tests"] + total_work["shadow_sphere_tests"]) * FLOP_PER_SPHERE_TEST
     # per launch = per rank: every rank runs the same kernel on 1/world of the frame
-    flops_per_launch = flops / world
+    flops_per_launch = flops if emu else flops / world
     achieved_tflops = flops_per_launch / (kernel_ms * 1e-3) / 1e12
     # algorithmic HBM bytes per launch: the rank's share of the ARGB frame + the scene once (workgroups re-read it from L2)
     hbm_bytes_per_launch = W * rows * 4 + len(scene) * 80
     achieved_gbps = hbm_bytes_per_launch / (kernel_ms * 1e-3) / 1e9
 
-    # Counters of the timed kernel per launch, from the rocprofv3 --pmc passes of this command committed under profiles/
-    # (counters cannot be collected from inside the run; the kernel TIME is measured live, above).  Quoted only for the
-    # workload they were collected on; with N ranks every rank runs the same kernel on 1/N of the rows.
-    pmc = None
+    # Counters of a timed step, from the rocprofv3 --pmc passes of this command committed under profiles/ (counters cannot
+    # be collected from inside the run; the kernel TIME is measured live, above).  Quoted only for the workload they were
+    # collected on AND the build they were collected on (hash of the kernel sources); with N ranks every rank runs the
+    # same kernels on 1/N of the rows.
+    pmc, stale = None, False
     try:
         with open(os.path.join(ROOT, "profiles", PMC_FILE)) as f:
             pmc = json.load(f).get(args.workload)
     except (OSError, ValueError):
         pass
-    traffic = pmc["hbm_bytes_per_launch"] / world if pmc else None
+    if pmc and pmc.get("source_sha256_16") != source_hash():
+        stale = True
     # with two contexts in flight (N > 1) consecutive kernels overlap: a launch's share of the device is the frame period
     kernel_s = (min(kernel_ms, ms_per_step) if pipelined else kernel_ms) * 1e-3
-    slot_flop = 64 * 2 * VALU_ISSUE_CYCLES / 2          # flop an FMA delivers in one issue slot of a wave64 instruction
-    if pmc:
-        valu = pmc["valu_instructions_per_launch"] / world
-        achieved = valu * slot_flop / kernel_s / 1e12    # issue-slot-equivalent TFLOP/s: every slot priced as an FMA
-        fp32 = pmc["fp32_flop_per_launch_upper_bound"] / world / kernel_s / 1e12
+    if pmc and not stale:
+        ps = pmc["per_step"]
+        traffic = ps["hbm_bytes"] / part_world
+        valu = ps["valu_instructions"] / part_world
+        fp32 = ps["fp32_flop_upper_bound"] / part_world / kernel_s / 1e12
+        dom = pmc["kernels"][pmc["dominant_kernel"]]
         roofline = {
-            "bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": traffic,
-            "valu_instructions_per_launch": valu, "salu_instructions_per_launch": pmc["salu_instructions_per_launch"] / world,
+            "bound": "valu", "achieved": fp32, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
+            "frac": fp32 / PEAK_FP32_VALU_TFLOPS, "traffic": traffic, "stale": False,
+            "note": "hardware-side, FP32 vector ALU (the bounding unit of this path, SURVEY.md 8d; not HBM, not MFMA): achieved = FP32 "
+                    "add + mul + 2 x fma + transcendental wave-instructions x 64 lanes executed per step (PMC, all lanes "
+                    "counted active: an upper bound) / the step's kernel time measured live in this run.  The kernels "
+                    "are built with -ffp-contract=off (bit-exact with the reference's operation order), so most FP32 "
+                    "instructions deliver 1 flop of the 2 an FMA would: see issue_slot_utilisation for how busy the VALUs are",
             "issue_slot_utilisation": valu * VALU_ISSUE_CYCLES / (SIMDS * CLOCK_GHZ * 1e9 * kernel_s),
-            "fp32_executed": {"achieved": fp32, "frac": fp32 / PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-                              "note": "FP32 add + mul + 2 x fma + transcendental wave-instructions x 64 lanes (all lanes "
-                                      "counted active: an upper bound); -ffp-contract=off makes most of them 1-flop "
-                                      "instructions, which by itself halves the reachable FP32 rate"},
-            "kernel": pmc["kernel"], "counters": "profiles/" + PMC_FILE,
-            "lds_bank_conflict_fraction": pmc.get("lds_bank_conflict_fraction"),
-            "mean_waves_per_simd": pmc.get("mean_waves_per_simd"), "wave_cycle_shares": pmc.get("wave_cycle_shares"),
-            "note": "hardware-side: achieved = VALU wave-instructions executed per launch (PMC SQ_INSTS_VALU%s) x 128 "
-                    "(the flop an FMA delivers in the 2-cycle issue slot every wave64 VALU instruction occupies) / kernel "
-                    "time measured in this run; frac = achieved / 157.3 = issue-slot utilisation of the 1024 SIMDs at "
-                    "2.4 GHz. The bounding unit is VALU instruction issue (FP32 vector ALU), not HBM and not MFMA "
-                    "(SURVEY.md 8d)." % ("" if world == 1 else ", N=1 pass / %d ranks" % world)}
+            "issue_slot_note": "VALU wave-instructions executed per step (SQ_INSTS_VALU%s) x 2 issue cycles / (1024 SIMDs x 2.4 GHz x "
+                               "kernel time): the share of VALU issue slots that hold an instruction of any kind (FP32, compare, "
+                               "select, lane read, integer)" % ("" if part_world == 1 else ", N=1 pass / %d ranks" % part_world),
+            "valu_instructions_per_step": valu, "salu_instructions_per_step": ps.get("salu_instructions", 0) / part_world,
+            "kernel": pmc["dominant_kernel"], "kernels_per_step": {k: v["trace"].get("launches_per_step") for k, v in pmc["kernels"].items()},
+            "dominant_kernel_trace_avg_ms": dom["trace"].get("avg_ns", 0) / 1e6,
+            "counters": "profiles/" + PMC_FILE, "source_sha256_16": pmc["source_sha256_16"],
+            "lds_bank_conflict_fraction": dom.get("lds_bank_conflict_fraction"),
+            "mean_waves_per_simd": dom.get("mean_waves_per_simd"), "wave_cycle_shares": dom.get("wave_cycle_shares")}
     else:
+        traffic = None
         roofline = {"bound": "valu", "achieved": None, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": None,
-                    "traffic": None, "note": "no PMC pass of this workload is committed under profiles/%s" % PMC_FILE}
+                    "traffic": None, "stale": stale,
+                    "note": ("the counters under profiles/%s were collected on another build of the kernels (source hash %s, this tree %s): "
+                             "not priced" % (PMC_FILE, pmc.get("source_sha256_16"), source_hash())) if stale else
+                            "no PMC pass of this workload is committed under profiles/%s" % PMC_FILE}
     algorithmic = {"achieved": achieved_tflops, "unit": "TFLOP/s", "x_over_hardware_peak": achieved_tflops / PEAK_FP32_VALU_TFLOPS,
                    "note": "ALGORITHMIC rate, not a hardware fraction: (triangle tests*46 + sphere tests*30 flop) of the "
                            "reference's brute-force loops per launch / kernel time. The kernel decides most (surface point, "
@@ -310,7 +350,9 @@ def main():
                     "(surface point, triangle) pairs the interval bounds leave undecided"}
 
     out = {
-        "metric": "Mrays/sec (nominal = W*H*AA*(1+S)/t), Cornell Box 4096^2, 8xAA, 64 shadow rays",
+        "metric": "Mrays/sec (nominal = W*H*AA*(1+S)/t), " + (
+            "Cornell Box 4096^2, 8xAA, 64 shadow rays" if args.workload == "headline" else
+            "workload %s: %dx%d, %dxAA, %d shadow rays, %d triangles (not the headline frame)" % (args.workload, W, H, aa, cfg.shadow_samples, len(scene))),
         "value": nominal_rays / (ms_per_step * 1e-3) / 1e6,
         "unit": "Mrays/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -322,13 +364,18 @@ def main():
         "data": "synthetic",
         "config": {"workload": "%s: Cornell Box %dx%d, %dx%d AA, %d shadow rays, %d spheres, <=%d bounces, %d triangles" % (
             args.workload, W, H, cfg.aa_x, cfg.aa_y, cfg.shadow_samples, cfg.num_spheres, cfg.max_bounces, len(scene)),
-            "parallelism": "row bands of %d over %d GPU(s) + RCCL gather" % (band_rows, world) if collective else "1 GPU"},
+            "parallelism": "row bands of %d over %d GPU(s) + RCCL gather" % (band_rows, part_world) if collective else "1 GPU"},
+        "host_enqueue_ms_per_step": host_enqueue_s * 1e3 / args.steps,
         "kernel_ms_per_launch": kernel_ms,
-        "traced_mrays_per_s": traced_rays / (ms_per_step * 1e-3) / 1e6,
-        "nominal_rays_per_frame": nominal_rays, "traced_rays_per_frame": traced_rays,
+        "traced_mrays_per_s": None if args.timed_only else traced_rays / (ms_per_step * 1e-3) / 1e6,
+        "nominal_rays_per_frame": nominal_rays, "traced_rays_per_frame": None if args.timed_only else traced_rays,
         "work_per_frame": total_work,
         "frame_checksum": frame_sum,
-        "parity": "bit-exact vs CPU oracle (strict FP32, reference operation order); tolerance allowed 1e-4",
+        "parity": "bit-exact vs the CPU oracle (strict FP32, reference operation order); oracle and product vs the reference ITSELF "
+                  "on this GPU's OpenCL device (kernels.cl built for gfx950 with AMD's OpenCL builtins and the reference's own options): "
+                  ">= 99.17 % of the pixels of every fixture frame within 1 LSB of its 8-bit output (= 1e-4 in colour; 99.83 % on the "
+                  "shipped 1024^2 frame, > 99.997 % from a general view), and every pixel beyond lies within 1 px of a ray/edge "
+                  "discontinuity (tests/test_oracle_ref_gpu.py, tests/test_gpu_ref_gpu.py)",
         "roofline": roofline,
         "algorithmic_speedup_vs_bruteforce": algorithmic,
         "roofline_hbm": {"bound": "hbm", "achieved": achieved_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
@@ -338,6 +385,15 @@ def main():
                                  "traffic = HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction) from the PMC "
                                  "passes in profiles/" + PMC_FILE},
     }
+
+    if emu:
+        out["emulated_rank"] = {
+            "rank": emu[0], "of": emu[1], "rows": rows, "steps_per_s": args.steps / elapsed,
+            "host_enqueue_ms_per_step": host_enqueue_s * 1e3 / args.steps, "gpu_kernel_ms_per_step": kernel_ms,
+            "note": "ONE process playing rank %d of %d and the root: its bands rendered by two contexts on two streams, gathered over RCCL "
+                    "into slot %d of the root's receive buffer, the root's de-interleave over all %d slots.  `value` is what the "
+                    "%d-GPU job would deliver if every rank took this long per step — a budget, not a measurement of that job; "
+                    "frame_checksum covers this rank's bands only" % (emu[0], emu[1], emu[0], emu[1], emu[1])}
 
     if not collective and not args.no_brute_force and "stage1_wave_iterations" in total_exec and args.workload == "headline":
         # the same frame with the interval cull switched off (every triangle tested for every surface point)
@@ -422,6 +478,8 @@ def main():
         from oracle import pyref
         rng = np.random.default_rng(12345)
         pix = rng.choice(W * H, size=4000, replace=False).astype(np.int32)
+        if emu:     # only this rank's bands were rendered
+            pix = pix[((pix // W) // band_rows) % part_world == part_rank]
         v, n, c = scene.packed()
         o_argb, _ = pyref.Oracle().render(abi.make_config(**wl), v, n, c, rot, cam, light, focal, pix=pix,
                                           nthreads=min(len(os.sched_getaffinity(0)), 16))
@@ -473,12 +531,66 @@ def main():
                           "x86-64 (oracle/_ref/libref_%s.so)" % (rpix.size, W, H, rcfg.aa_x, rcfg.aa_y, rcfg.shadow_samples, refv),
                 "port_on_same_sample": rrays / pdt / 1e6,
                 "port_matches_reference_kernel": bool(np.array_equal(r_argb, p_argb))}
+        # Is there an OpenCL CPU device on this box (the reference enumerates devices at skeleton.cpp:516-573)?
+        # And the reference's own kernel on the OpenCL device that IS here — this GPU: kernels.cl built for gfx950 against
+        # AMD's OpenCL builtins with the reference's options (oracle/_ref/*.co), launched through the OpenCL runtime in a
+        # process of its own (oracle/ref_cl_host.c), next to this library on the SAME configuration.
+        from oracle import ref_gpu
+        probe = ref_gpu.probe()
+        out["cpu_baseline"]["opencl_cpu_devices"] = probe.get("opencl_cpu_devices", probe.get("error", "probe failed"))
+        out["cpu_baseline"]["opencl_platforms"] = probe.get("platforms", probe.get("error"))
+        refg = {"reference": ("default", {}), "cfg2": ("cfg2", {}), "cfg3": ("cfg3", {}),
+                "headline": ("s64_4096", dict(aa_x=2, aa_y=2))}.get(args.workload)
+        if refg and len(scene) == 26 and ref_gpu.have(refg[0]) and probe.get("opencl_gpu_devices", 0) > 0:
+            variant, over = refg
+            gcfg = abi.make_config(**dict(wl, **over))
+            gaa = gcfg.aa_x * gcfg.aa_y
+            gfocal = 1100.0 * min(W, H) / 1024.0 * gcfg.aa_x
+            torch.cuda.synchronize()
+            try:
+                g_argb, info = ref_gpu.run(variant, W, H, v, n, c, rot, cam, light, gfocal, reps=3)
+                gt = rt.RayTracer(abi.make_config(device=local_rank, **dict(wl, **over)), scene)
+                gbuf = torch.empty((H, W), dtype=torch.int32, device=dev)
+                for _ in range(6):
+                    gt.render_device(rot, cam, light, gfocal, gbuf.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    gt.render_device(rot, cam, light, gfocal, gbuf.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+                e1.record()
+                torch.cuda.synchronize()
+                oms = e0.elapsed_time(e1) / 10
+                gt.close()
+                ours = gbuf.cpu().numpy().view(np.uint32).ravel()
+                chd = np.zeros(ours.shape, np.int32)
+                for sh in (0, 8, 16):
+                    chd = np.maximum(chd, np.abs(((ours >> sh) & 255).astype(np.int32) - ((g_argb >> sh) & 255).astype(np.int32)))
+                grays = W * H * gaa * (1 + gcfg.shadow_samples)
+                out["reference_opencl_on_this_gpu"] = {
+                    "kernel_ms": info["kernel_ms_mean"], "value": grays / (info["kernel_ms_mean"] * 1e-3) / 1e6, "unit": "Mrays/s",
+                    "device": info["device"], "work_group": info["local"], "kind": "reference",
+                    "config": "%dx%d, %dx%d AA, %d shadow rays (%s)" % (W, H, gcfg.aa_x, gcfg.aa_y, gcfg.shadow_samples,
+                              "the workload itself" if not over else "2x2 AA: the reference cannot express the headline's 4x2 grid"),
+                    "this_library_same_config": {"kernel_ms": oms, "value": grays / (oms * 1e-3) / 1e6, "speedup": info["kernel_ms_mean"] / oms},
+                    "pixels_within_1_lsb": float((chd <= 1).mean()), "pixels_identical": float((chd == 0).mean()),
+                    "note": "the reference's kernels.cl compiled for gfx950 against AMD's own OpenCL builtin library with its own "
+                            "options (-cl-fast-relaxed-math -cl-mad-enable), run through the OpenCL runtime on this MI355X by "
+                            "oracle/ref_cl_host (128x2 work-groups: AMD's OpenCL refuses the reference's 128x4); pixels beyond 1 LSB "
+                            "sit on ray/edge discontinuities (tests/refgpu_check.py)"}
+            except Exception as e:      # noqa: BLE001 - a baseline leg must not take the bench line down
+                out["reference_opencl_on_this_gpu"] = {"error": "%s: %s" % (type(e).__name__, e)}
         # the sampled pixels double as an in-bench parity check of the frame just timed
         got = (stripe if world == 1 else frame).view(-1)[torch.from_numpy(pix.astype(np.int64)).to(dev)].cpu().numpy().view(np.uint32)
         out["cpu_baseline"]["gpu_frame_matches_oracle_on_sample"] = bool(np.array_equal(got, o_argb))
 
-    print(json.dumps(out))
+    sys.stdout.flush()
+    if saved_stdout is not None:
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
+    print(json.dumps(out), flush=True)
     if collective:
+        os.dup2(2, 1)           # (anything the teardown prints goes to stderr as well)
         dist.destroy_process_group()
 
 

@@ -23,7 +23,7 @@ def padded_rows(height, world, band_rows):
     return -(-nbands // world) * band_rows
 
 
-def gather_frame(stripe, world, rank, band_rows, recv=None, frame=None, dst=0, force=False, height=None):
+def gather_frame(stripe, world, rank, band_rows, recv=None, frame=None, dst=0, force=False, height=None, emulate=False):
     """Gather every rank's packed bands to `dst` and de-interleave them into image order.
 
     stripe: [padded_rows, W] integer tensor (ARGB words) on this rank, the rows it owns packed at the top.  `recv`:
@@ -31,7 +31,9 @@ def gather_frame(stripe, world, rank, band_rows, recv=None, frame=None, dst=0, f
     land in one allocation and the de-interleave is a single strided copy).  `frame`: optional preallocated
     [padded_rows * world, W] buffer.  Returns the [height, W] frame on `dst` (a view of `frame`) and None elsewhere.
     With world == 1 the stripe is the frame and no collective runs, unless `force` (used to exercise the collective on
-    one rank).
+    one rank).  `emulate`: this ONE process plays rank `rank` of a `world`-rank job and the root at once (bench.py
+    --emulate-rank): its stripe is gathered into slot `rank` of the root's receive buffer and the root's de-interleave runs
+    over all `world` slots — the per-step work of the root of a real job, minus the other ranks' transfers.
     """
     import torch
     import torch.distributed as dist
@@ -40,11 +42,14 @@ def gather_frame(stripe, world, rank, band_rows, recv=None, frame=None, dst=0, f
     rows, width = stripe.shape
     if rows % band_rows:
         raise ValueError("the stripe must hold whole bands: %d rows, bands of %d (see padded_rows)" % (rows, band_rows))
-    if rank == dst and recv is None:
+    if (rank == dst or emulate) and recv is None:
         recv = torch.empty((world, rows, width), dtype=stripe.dtype, device=stripe.device)
-    dist.gather(stripe, [recv[r] for r in range(world)] if rank == dst else None, dst=dst)
-    if rank != dst:
-        return None
+    if emulate:
+        dist.gather(stripe, [recv[rank]], dst=0)
+    else:
+        dist.gather(stripe, [recv[r] for r in range(world)] if rank == dst else None, dst=dst)
+        if rank != dst:
+            return None
     if frame is None:
         frame = torch.empty((rows * world, width), dtype=stripe.dtype, device=stripe.device)
     # [rank, band, row, x] -> [band, rank, row, x] == image order
