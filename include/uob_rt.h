@@ -182,6 +182,26 @@ int rt_unregister_output(rt_ctx* ctx);
  * RT_E_UNSUPPORTED when the context was not created with the knob set or its last frame ran on another kernel. */
 int rt_debug_wave_timeline(rt_ctx* ctx, uint64_t out[8]);
 
+/* Diagnostic, several devices in one context (rt_config.devices): the copies that carry device k's packed bands
+ * (bands k, k+N, ... of device_band_rows rows, owned rows packed top to bottom in its stripe) to image order in a
+ * destination frame of `width` x `height` elements of elem_bytes — exactly what rt_render / rt_render_device enqueue
+ * for a device that does not write the destination itself.  Pure arithmetic, no device needed: the cross-device branches
+ * cannot run on a one-GPU machine, so tests check and replay the plan on the CPU (tests/test_band_copy_plan.py).
+ *   dev_to_dev   : 0 = into host memory (rt_render), 1 = into the root device's memory (rt_render_device)
+ *   peer_ok      : the source device may copy 2-D into the root's memory directly (hipDeviceEnablePeerAccess succeeded)
+ *   same_device  : the source device IS the root device
+ * Writes min(count, cap) entries, returns the count (or a negative RT_E_* code).  Offsets and pitches are in bytes.     */
+enum { RT_COPY_2D = 0,      /* hipMemcpy2DAsync: `rows` rows of width_bytes, source pitch src_pitch, destination pitch dst_pitch */
+       RT_COPY_PEER = 1,    /* hipMemcpyPeerAsync of width_bytes bytes (no peer mapping, or the ragged last band across devices) */
+       RT_COPY_LINEAR = 2   /* hipMemcpyAsync of width_bytes bytes (ragged last band, same device or to the host)          */ };
+typedef struct rt_band_copy {
+  int32_t op, reserved;
+  uint64_t dst_offset, dst_pitch, src_offset, src_pitch, width_bytes, rows;
+} rt_band_copy;
+int rt_debug_band_copy_plan(int32_t num_devices, int32_t k, int32_t device_band_rows, int32_t width, int32_t height,
+                            int32_t elem_bytes, int32_t dev_to_dev, int32_t peer_ok, int32_t same_device,
+                            rt_band_copy* out, int32_t cap);
+
 /* On-device self test of the exact-reciprocal building block (rt_math.h rcp_newton): sweeps all 2^32
  * FP32 patterns and compares v_rcp_f32 + 1/2 Newton steps with the correctly rounded 1.0f/x.
  * out[0],out[1] = mismatches (1-step, 2-step) for 2^-100 <= |x| <= 2^100; out[2],out[3] = mismatches for
@@ -189,6 +209,9 @@ int rt_debug_wave_timeline(rt_ctx* ctx, uint64_t out[8]);
 int rt_selftest_rcp(uint64_t out[64]);
 
 void rt_destroy(rt_ctx* ctx);
+/* Message of the last failure on the calling thread.  After an RT_OK from rt_init / rt_render_device of a multi-device
+ * context it may instead hold a line that starts with "warning:" — a device without peer access to the root device
+ * works, through slower copies (band by band), and says so here.                                                      */
 const char* rt_last_error(void);
 int rt_abi_version(void);
 

@@ -39,6 +39,14 @@ class RtWork(C.Structure):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
 
 
+class RtBandCopy(C.Structure):
+    _fields_ = [("op", C.c_int32), ("reserved", C.c_int32)] + [(k, C.c_uint64) for k in (
+        "dst_offset", "dst_pitch", "src_offset", "src_pitch", "width_bytes", "rows")]
+
+
+RT_COPY_2D, RT_COPY_PEER, RT_COPY_LINEAR = 0, 1, 2
+
+
 class RtTriangle(C.Structure):
     _fields_ = [(k, C.c_float * 4) for k in ("v0", "v1", "v2", "normal", "color")]
 

@@ -3,10 +3,13 @@
 // Same globals and function names as the reference: focal_length, camera_position, yaw, pitch,
 // light_position (skeleton.cpp:61-67), update() (:282-361), draw via offload_rendering() (:146-182),
 // opencl_initialise() (:366-497) — the last two now four lines each over the C ABI.
-// SDL events do not exist headless: update() keeps the light animation (:290-298) bit for bit and takes the
-// camera controls from an optional script of key names ("up down left right i o k j", :312-352).
+// SDL events do not exist headless: update() keeps the light animation (:290-298) bit for bit and takes its events from
+// an optional script that stands for SDL's event queue: key names ("up down left right i o k j esc", :311-352), mouse
+// motion "m:dx,dy" (SDL_MOUSEMOTION xrel / yrel, :306-309) and "." (the queue is empty for the rest of this frame).
+// As in the reference's polling loop a frame consumes mouse events until it meets a key (handled, then update()
+// returns: what is left waits for the next frame), a "." or the end of the script.
 //
-//   uob_raytracer [--size N] [--frames K] [--aa X Y] [--shadows S] [--keys "left left i"] [--out file.bmp]
+//   uob_raytracer [--size N] [--frames K] [--aa X Y] [--shadows S] [--keys "left m:12,-3 . left i"] [--out file.bmp]
 //                 [--obj mesh.obj]            append load_obj(mesh.obj) to the box, as skeleton.cpp:102-103 does
 //                 [--gpus N | --devices a,b,..]  render every frame on several GPUs inside the one context
 //                 [--copy-back]                  device buffer + blocking read-back instead of rt_register_output
@@ -68,8 +71,16 @@ bool update() {                                                // :282-361
     if (diff < 0.001f) lor = true;
     light_position[0] += diff / 20.0f;
   }
-  if (g_key_at < g_keys.size()) {                              // one scripted "SDL_KEYDOWN" per frame, :311-352
+  while (g_key_at < g_keys.size()) {                           // while(SDL_PollEvent(&e)), :300-301
     const string& k = g_keys[g_key_at++];
+    if (k == ".") return false;                                // no more events this frame
+    if (k.compare(0, 2, "m:") == 0) {                          // SDL_MOUSEMOTION, :306-309
+      int xrel = 0, yrel = 0;
+      if (sscanf(k.c_str() + 2, "%d,%d", &xrel, &yrel) != 2) { fprintf(stderr, "bad mouse event '%s' (m:dx,dy)\n", k.c_str()); exit(2); }
+      yaw += xrel * 0.0009f;
+      pitch -= yrel * 0.0009f;
+      continue;
+    }
     if (k == "up") pitch -= 0.1;
     else if (k == "down") pitch += 0.1;
     else if (k == "left") yaw += 0.1;

@@ -294,6 +294,7 @@ static int init_parent(const rt_config* cfg, const float* vertices4, const float
     }
   rt_ctx* p = new (std::nothrow) rt_ctx();
   if (!p) { set_error("out of host memory"); return RT_E_NOMEM; }
+  std::string downgrade;                     // devices that will copy band by band (reported through rt_last_error)
   p->cfg = *cfg;
   p->device = cfg->devices[0];
   p->n = n;
@@ -313,19 +314,28 @@ static int init_parent(const rt_config* cfg, const float* vertices4, const float
     }
     if (k->device != p->device) {           // let the copy engines of this device write the root's memory directly
       int can = 0;
-      if (hipDeviceCanAccessPeer(&can, k->device, p->device) == hipSuccess && can) {
-        const hipError_t e = hipDeviceEnablePeerAccess(p->device, 0);
+      hipError_t e = hipDeviceCanAccessPeer(&can, k->device, p->device);
+      if (e == hipSuccess && can) {
+        e = hipDeviceEnablePeerAccess(p->device, 0);
         k->peer_ok = (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled);
       } else {
         k->peer_ok = false;
       }
       (void)hipGetLastError();
+      if (!k->peer_ok) {                     // not an error: the bands travel band by band through hipMemcpyPeerAsync — but say so
+        char line[160];
+        snprintf(line, sizeof line, "%sdevice %d has no peer access to device %d (%s)", downgrade.empty() ? "warning: " : "; ",
+                 k->device, p->device, e == hipSuccess ? "hipDeviceCanAccessPeer: no" : hipGetErrorString(e));
+        downgrade += line;
+      }
     }
   }
   if (hipSetDevice(p->device) != hipSuccess || hipEventCreateWithFlags(&p->ev_go, hipEventDisableTiming) != hipSuccess ||
       hipStreamCreate(&p->stream) != hipSuccess || hipEventCreate(&p->ev0) != hipSuccess || hipEventCreate(&p->ev1) != hipSuccess) {
     set_error("stream/event creation failed on device %d", p->device); rt_destroy(p); return RT_E_DEVICE;
   }
+  // RT_OK with a "warning: ..." line in rt_last_error(): the context works, through the slower copies
+  if (!downgrade.empty()) set_error("%s: their bands are copied band by band (hipMemcpyPeerAsync)", downgrade.c_str());
   *out_ctx = p;
   return RT_OK;
 }
@@ -515,15 +525,26 @@ static void fill_params(const rt_ctx* c, const float rot[12], const float cam[3]
     const long waves = (long)P->wave_blocks * 4;
     int jt = wave_aa ? 64 / pt : 1;                      // tasks of a 64-pixel job (aa for the power-of-two grids)
     while (jt > 1 && ((jt + 1) / 2) * pt >= 16 && (long)((g.width + jt * pt - 1) / (jt * pt)) * c->owned_rows < 16 * waves) jt = (jt + 1) / 2;
-    if (wave_aa && c->tune.job_tasks >= 1 && c->tune.job_tasks * pt <= 64) jt = c->tune.job_tasks;
+    // (the knob may not make a job smaller than 16 pixels: div_magic's exactness bound, rt_device.h, is stated for >= 16)
+    if (wave_aa && c->tune.job_tasks >= 1 && c->tune.job_tasks * pt <= 64 && (c->tune.job_tasks * pt >= 16 || c->tune.job_tasks >= jt))
+      jt = c->tune.job_tasks;
+    // job / nseg by one multiply-high (rt_device.h div_magic) is exact while (njobs - 1) * (magic * nseg - 2^32) < 2^32.
+    // Every accepted frame with jobs of 16+ pixels satisfies it; a knob that asks for smaller jobs is honoured only as far
+    // as the bound still holds (checked here, not assumed): the job is doubled until it does.
+    int job_pixels = 0;
+    for (;;) {
+      job_pixels = jt * pt;
+      P->nseg = (g.width + job_pixels - 1) / job_pixels;
+      P->njobs = P->nseg * c->owned_rows;
+      P->nseg_magic = P->nseg > 1 ? (uint32_t)((0x100000000ull + (uint64_t)P->nseg - 1) / (uint64_t)P->nseg) : 0u;
+      const uint64_t err = P->nseg_magic ? (uint64_t)P->nseg_magic * (uint64_t)P->nseg - 0x100000000ull : 0ull;
+      if ((uint64_t)(P->njobs > 0 ? P->njobs - 1 : 0) * err < 0x100000000ull || 2 * jt * pt > 64) break;
+      jt *= 2;
+    }
     P->job_tasks = jt;
     // (measured on one rank's 512 rows of the headline frame, whose longest jobs last 0.5 of its 0.57 ms: 0.570 ms with,
     // 0.566 without — the span is set by the work per wave and the ~60 us tail, not by the longest job; off unless asked for)
     P->split_listed = c->tune.split_listed == 1 && jt > 1 ? 1 : 0;
-    const int job_pixels = jt * pt;
-    P->nseg = (g.width + job_pixels - 1) / job_pixels;
-    P->njobs = P->nseg * c->owned_rows;
-    P->nseg_magic = P->nseg > 1 ? (uint32_t)((0x100000000ull + (uint64_t)P->nseg - 1) / (uint64_t)P->nseg) : 0u;
     P->job_hx = 0.5f * (float)(job_pixels * g.aa_x - 1);
     P->job_hy = 0.5f * (float)(g.aa_y - 1) * P->sy;
     for (int k = 0; k < 3; ++k)
@@ -634,33 +655,69 @@ static int launch_frame(rt_ctx* c, const float rot[12], const float cam[3], cons
 
 // ---- several devices --------------------------------------------------------------------------------------
 // Child k of a parent with N children owns the bands k, k+N, ... of `dbr` rows; its stripe holds them packed.
-// Copy them to image order at `dst` (row pitch W elements of `elem` bytes) — one 2-D copy whose "rows" are whole
-// bands, plus the ragged last band if this child owns it.
-static int deliver_bands(rt_ctx* p, int k, const void* stripe, void* dst, size_t elem, hipMemcpyKind kind, hipStream_t stream) {
-  rt_ctx* c = p->kids[k];
-  const int N = (int)p->kids.size(), dbr = p->cfg.device_band_rows, W = p->cfg.width;
+// band_copy_plan lists the copies that put them into image order at the destination (row pitch W elements of `elem`
+// bytes): one 2-D copy whose "rows" are whole bands, plus the ragged last band if this child owns it.  The plan is
+// pure arithmetic (no HIP call): rt_debug_band_copy_plan exposes it so that a CPU test can check every offset and pitch
+// and replay it with memcpy — the cross-device branches cannot run on a one-GPU box.
+static int band_copy_plan(int N, int k, int dbr, int W, int owned_rows, size_t elem, bool dev_to_dev, bool peer_ok,
+                          bool same_device, rt_band_copy* out, int cap) {
   const size_t band_bytes = (size_t)dbr * W * elem;
-  const int full = c->owned_rows / dbr, rem = c->owned_rows % dbr;
-  char* const d0 = (char*)dst + (size_t)k * band_bytes;
+  const int full = owned_rows / dbr, rem = owned_rows % dbr;
+  const size_t d0 = (size_t)k * band_bytes;
+  int cnt = 0;
+  auto emit = [&](int op, size_t doff, size_t dpitch, size_t soff, size_t spitch, size_t width, size_t rows) {
+    if (cnt < cap && out) {
+      rt_band_copy& c = out[cnt];
+      c.op = op; c.reserved = 0; c.dst_offset = doff; c.dst_pitch = dpitch; c.src_offset = soff; c.src_pitch = spitch;
+      c.width_bytes = width; c.rows = rows;
+    }
+    ++cnt;
+  };
   if (full > 0) {
-    hipError_t e = hipErrorUnknown;
-    if (kind != hipMemcpyDeviceToDevice || c->peer_ok)
-      e = hipMemcpy2DAsync(d0, (size_t)N * band_bytes, stripe, band_bytes, band_bytes, (size_t)full, kind, stream);
-    if (e != hipSuccess && kind == hipMemcpyDeviceToDevice) {        // no peer mapping: band by band through the runtime
-      (void)hipGetLastError();
+    if (!dev_to_dev || peer_ok) {
+      emit(RT_COPY_2D, d0, (size_t)N * band_bytes, 0, band_bytes, band_bytes, (size_t)full);
+    } else {                                   // no peer mapping: band by band through the runtime
       for (int b = 0; b < full; ++b)
-        HIP_TRY(hipMemcpyPeerAsync(d0 + (size_t)b * N * band_bytes, p->device, (const char*)stripe + (size_t)b * band_bytes,
-                                   c->device, band_bytes, stream));
-    } else if (e != hipSuccess) {
-      set_error("hipMemcpy2DAsync failed: %s", hipGetErrorString(e)); return RT_E_DEVICE;
+        emit(RT_COPY_PEER, d0 + (size_t)b * N * band_bytes, 0, (size_t)b * band_bytes, 0, band_bytes, 1);
     }
   }
   if (rem > 0) {
     const size_t bytes = (size_t)rem * W * elem;
-    char* const d1 = d0 + (size_t)full * N * band_bytes;
-    const char* const s1 = (const char*)stripe + (size_t)full * band_bytes;
-    if (kind == hipMemcpyDeviceToDevice && c->device != p->device) HIP_TRY(hipMemcpyPeerAsync(d1, p->device, s1, c->device, bytes, stream));
-    else HIP_TRY(hipMemcpyAsync(d1, s1, bytes, kind, stream));
+    emit(dev_to_dev && !same_device ? RT_COPY_PEER : RT_COPY_LINEAR, d0 + (size_t)full * N * band_bytes, 0,
+         (size_t)full * band_bytes, 0, bytes, 1);
+  }
+  return cnt;
+}
+
+static int deliver_bands(rt_ctx* p, int k, const void* stripe, void* dst, size_t elem, hipMemcpyKind kind, hipStream_t stream) {
+  rt_ctx* c = p->kids[k];
+  const int N = (int)p->kids.size(), dbr = p->cfg.device_band_rows, W = p->cfg.width;
+  const bool d2d = kind == hipMemcpyDeviceToDevice;
+  const int full = c->owned_rows / dbr;
+  std::vector<rt_band_copy> plan((size_t)full + 2);
+  int cnt = band_copy_plan(N, k, dbr, W, c->owned_rows, elem, d2d, c->peer_ok, c->device == p->device, plan.data(), (int)plan.size());
+  for (int i = 0; i < cnt; ++i) {
+    const rt_band_copy& q = plan[(size_t)i];
+    char* const d = (char*)dst + q.dst_offset;
+    const char* const sp = (const char*)stripe + q.src_offset;
+    if (q.op == RT_COPY_2D) {
+      const hipError_t e = hipMemcpy2DAsync(d, q.dst_pitch, sp, q.src_pitch, q.width_bytes, q.rows, kind, stream);
+      if (e != hipSuccess && d2d && c->device != p->device) {
+        // the direct 2-D copy was refused after all: from now on this device copies band by band through the runtime
+        (void)hipGetLastError();
+        c->peer_ok = false;
+        set_error("warning: device %d cannot copy 2-D into device %d (%s): its bands go band by band through hipMemcpyPeerAsync",
+                  c->device, p->device, hipGetErrorString(e));
+        cnt = band_copy_plan(N, k, dbr, W, c->owned_rows, elem, d2d, false, false, plan.data(), (int)plan.size());
+        i = -1;
+        continue;
+      }
+      if (e != hipSuccess) { set_error("hipMemcpy2DAsync failed: %s", hipGetErrorString(e)); return RT_E_DEVICE; }
+    } else if (q.op == RT_COPY_PEER) {
+      HIP_TRY(hipMemcpyPeerAsync(d, p->device, sp, c->device, q.width_bytes, stream));
+    } else {
+      HIP_TRY(hipMemcpyAsync(d, sp, q.width_bytes, kind, stream));
+    }
   }
   return RT_OK;
 }
@@ -669,39 +726,63 @@ static int parent_render(rt_ctx* p, const float rot[12], const float cam[3], con
                          uint32_t* host_argb, float* host_rgb, uint32_t* d_argb, float4* d_rgb, hipStream_t caller) {
   const bool to_host = host_argb != nullptr;
   const size_t W = (size_t)p->cfg.width;
+  const size_t nk = p->kids.size();
   if (!to_host) {                                     // the caller's earlier work on the destination comes first
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipEventRecord(p->ev0, caller));
     HIP_TRY(hipEventRecord(p->ev_go, caller));
   }
-  for (size_t k = 0; k < p->kids.size(); ++k) {
+  const bool want_rgb = to_host ? host_rgb != nullptr : d_rgb != nullptr;
+  std::vector<char> launched(nk, 0), direct(nk, 0);
+  // On an error the devices already launched may still be writing into the caller's buffers: wait for them before returning
+  auto fail = [&](int rc) {
+    const std::string msg = g_last_error;
+    for (size_t k = 0; k < nk; ++k)
+      if (launched[k]) { hipSetDevice(p->kids[k]->device); hipStreamSynchronize(p->kids[k]->stream); }
+    (void)hipGetLastError();
+    g_last_error = msg;
+    return rc;
+  };
+  // pass 1: every device's frame is launched before any band is delivered.  (Delivering inside this loop made the host
+  // thread wait for device k's kernel and copy — a device-to-pageable-host copy blocks — before it launched device k+1:
+  // the devices then ran one after another.)
+  for (size_t k = 0; k < nk; ++k) {
     rt_ctx* c = p->kids[k];
     if (c->owned_rows == 0) continue;
-    HIP_TRY(hipSetDevice(c->device));
-    const bool want_rgb = to_host ? host_rgb != nullptr : d_rgb != nullptr;
-    if (want_rgb && !c->d_rgb) HIP_TRY(hipMalloc(&c->d_rgb, (size_t)c->owned_rows * W * sizeof(float4)));
-    if (!to_host) HIP_TRY(hipStreamWaitEvent(c->stream, p->ev_go, 0));
+    if (hipSetDevice(c->device) != hipSuccess) { set_error("hipSetDevice(%d) failed", c->device); return fail(RT_E_DEVICE); }
+    if (want_rgb && !c->d_rgb && hipMalloc(&c->d_rgb, (size_t)c->owned_rows * W * sizeof(float4)) != hipSuccess) {
+      set_error("hipMalloc failed (float tap, device %d)", c->device); return fail(RT_E_NOMEM);
+    }
+    if (!to_host && hipStreamWaitEvent(c->stream, p->ev_go, 0) != hipSuccess) { set_error("hipStreamWaitEvent failed"); return fail(RT_E_DEVICE); }
     // a device that holds the destination writes its rows there itself; the others render into their stripe.  A registered
     // host framebuffer (rt_register_output) is held by every device: each writes its bands into it over its own PCIe link.
     const bool mapped = to_host && !host_rgb && c->reg_host && (char*)host_argb >= c->reg_host &&
                         (char*)host_argb + (size_t)p->cfg.height * W * 4 <= c->reg_host + c->reg_bytes &&
                         !(p->cfg.flags & RT_FLAG_STAGED_GATHER);
-    const bool direct = mapped || (!to_host && c->device == p->device && !(p->cfg.flags & RT_FLAG_STAGED_GATHER));
+    direct[k] = mapped || (!to_host && c->device == p->device && !(p->cfg.flags & RT_FLAG_STAGED_GATHER));
     uint32_t* const dst = mapped ? reinterpret_cast<uint32_t*>(c->reg_dev + ((char*)host_argb - c->reg_host)) : d_argb;
-    int rc = direct ? launch_frame(c, rot, cam, light, focal, dst, mapped ? nullptr : d_rgb, c->stream, true)
-                    : launch_frame(c, rot, cam, light, focal, c->d_argb, want_rgb ? c->d_rgb : nullptr, c->stream);
-    if (rc != RT_OK) return rc;
-    if (!direct) {
+    const int rc = direct[k] ? launch_frame(c, rot, cam, light, focal, dst, mapped ? nullptr : d_rgb, c->stream, true)
+                             : launch_frame(c, rot, cam, light, focal, c->d_argb, want_rgb ? c->d_rgb : nullptr, c->stream);
+    if (rc != RT_OK) return fail(rc);
+    launched[k] = 1;
+  }
+  // pass 2: the copy engines deliver the bands, every device on its own stream behind its own kernel
+  for (size_t k = 0; k < nk; ++k) {
+    rt_ctx* c = p->kids[k];
+    if (!launched[k]) continue;
+    if (hipSetDevice(c->device) != hipSuccess) { set_error("hipSetDevice(%d) failed", c->device); return fail(RT_E_DEVICE); }
+    if (!direct[k]) {
       const hipMemcpyKind kind = to_host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
-      rc = deliver_bands(p, (int)k, c->d_argb, to_host ? (void*)host_argb : (void*)d_argb, 4, kind, c->stream);
+      int rc = deliver_bands(p, (int)k, c->d_argb, to_host ? (void*)host_argb : (void*)d_argb, 4, kind, c->stream);
       if (rc == RT_OK && want_rgb)
         rc = deliver_bands(p, (int)k, c->d_rgb, to_host ? (void*)host_rgb : (void*)d_rgb, sizeof(float4), kind, c->stream);
-      if (rc != RT_OK) return rc;
+      if (rc != RT_OK) return fail(rc);
     }
-    if (!to_host) HIP_TRY(hipEventRecord(c->ev_done, c->stream));
+    if (!to_host && hipEventRecord(c->ev_done, c->stream) != hipSuccess) { set_error("hipEventRecord failed"); return fail(RT_E_DEVICE); }
   }
   if (to_host) {
     for (rt_ctx* c : p->kids) if (c->owned_rows) { HIP_TRY(hipSetDevice(c->device)); HIP_TRY(hipStreamSynchronize(c->stream)); }
+    p->timed = false;             // rt_last_kernel_ms: this frame's time is the children's, not an older device-path interval
   } else {
     HIP_TRY(hipSetDevice(p->device));
     for (rt_ctx* c : p->kids) if (c->owned_rows) HIP_TRY(hipStreamWaitEvent(caller, c->ev_done, 0));
@@ -924,6 +1005,21 @@ int rt_debug_trace_rays(rt_ctx* c, int32_t what, const float* rays6, const float
   }
   hipFree(d_rays); hipFree(d_r2); hipFree(d_out); hipFree(d_tri);
   return rc;
+}
+
+int rt_debug_band_copy_plan(int32_t num_devices, int32_t k, int32_t device_band_rows, int32_t width, int32_t height,
+                            int32_t elem_bytes, int32_t dev_to_dev, int32_t peer_ok, int32_t same_device,
+                            rt_band_copy* out, int32_t cap) {
+  if (num_devices < 1 || num_devices > RT_MAX_DEVICES || k < 0 || k >= num_devices || device_band_rows < 0 || width < 1 ||
+      height < 1 || elem_bytes < 1 || cap < 0 || (!out && cap > 0)) {
+    set_error("rt_debug_band_copy_plan: invalid argument"); return RT_E_INVALID;
+  }
+  const int dbr = device_band_rows > 0 ? device_band_rows : 32;
+  rt_config kc;
+  memset(&kc, 0, sizeof kc);
+  kc.height = height; kc.band_rows = dbr; kc.band_index = k; kc.band_count = num_devices;
+  return band_copy_plan(num_devices, k, dbr, width, rt_config_owned_rows(&kc), (size_t)elem_bytes, dev_to_dev != 0, peer_ok != 0,
+                        same_device != 0, out, cap);
 }
 
 int rt_debug_block_costs(rt_ctx* c, uint32_t* out, int32_t cap) {

@@ -135,9 +135,21 @@ int rt_scene_load_obj_ex(const char* path, const float color[4], float scale, co
   if (!f) { uobrt::set_error("rt_scene_load_obj: cannot open %s", path); return RT_E_IO; }
   std::vector<P3> verts;
   int n = 0, rc = RT_OK;
-  char line[1024];
+  // Lines of any length (an n-gon's `f` record can be thousands of characters): a fixed buffer would cut a record in two
+  // and read the second half as a record of its own, indices split mid-number.
+  std::string linebuf;
+  char chunk[1024];
   long lineno = 0;
-  while (fgets(line, sizeof line, f)) {
+  for (;;) {
+    linebuf.clear();
+    bool got = false;
+    while (fgets(chunk, sizeof chunk, f)) {
+      got = true;
+      linebuf += chunk;
+      if (!linebuf.empty() && linebuf.back() == '\n') break;
+    }
+    if (!got) break;
+    const char* const line = linebuf.c_str();
     ++lineno;
     char tag[8] = {0};
     int used = 0;
@@ -150,7 +162,7 @@ int rt_scene_load_obj_ex(const char* path, const float color[4], float scale, co
       // Loader.cpp:44-45 reads three plain 1-based indices.  Hardening beyond the reference (which reads
       // garbage there): "i/t/n" and "i//n" tokens (the vertex index is taken), negative = relative indices,
       // and polygons with more than three corners, fan-triangulated in order.
-      int idx[64];
+      std::vector<int> idx;
       int k = 0;
       const int nv = (int)verts.size();
       const char* p = line + used;
@@ -160,7 +172,7 @@ int rt_scene_load_obj_ex(const char* path, const float color[4], float scale, co
         if (*p == '\0' || *p == '\n' || *p == '\r' || *p == '#') break;
         char* end = nullptr;
         long v = strtol(p, &end, 10);
-        if (end == p || k == 64) { bad = true; break; }
+        if (end == p) { bad = true; break; }
         p = end;
         while (*p && *p != ' ' && *p != '\t' && *p != '\n' && *p != '\r') {      // "/t/n" suffix
           if (*p != '/' && *p != '-' && (*p < '0' || *p > '9')) { bad = true; break; }
@@ -169,7 +181,7 @@ int rt_scene_load_obj_ex(const char* path, const float color[4], float scale, co
         if (bad) break;
         if (v < 0) v = nv + 1 + v;
         if (v < 1 || v > nv) { bad = true; break; }
-        idx[k++] = (int)v;
+        idx.push_back((int)v); ++k;
       }
       if (bad || k < 3) { rc = RT_E_IO; break; }
       for (int j = 1; j + 1 < k; ++j) {

@@ -8,6 +8,15 @@ import os
 
 import numpy as np
 
+# Two HIP runtimes can end up in one process: torch ships its own libamdhip64, libuob_rt.so links the system's.  Loaded in
+# the order torch -> libuob_rt.so both work; the other order ends in "No HIP GPUs are available" from torch.  So: if torch
+# is installed, it is imported here, before lib() can load the library (torch is plumbing for tests and bench.py; the
+# library itself needs none of it).
+try:
+    import torch as _torch  # noqa: F401
+except ImportError:          # a host without torch: nothing to order
+    _torch = None
+
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -18,6 +27,7 @@ EXPORTS = (
     "rt_render_device", "rt_count_work", "rt_count_executed", "rt_last_kernel_ms", "rt_destroy", "rt_scene_cornell_box",
     "rt_scene_load_obj", "rt_scene_load_obj_ex", "rt_triangle_compute_normal", "rt_scene_pack", "rt_rotation_matrix",
     "rt_selftest_rcp", "rt_debug_trace_rays", "rt_debug_block_costs", "rt_debug_wave_timeline", "rt_register_output", "rt_unregister_output",
+    "rt_debug_band_copy_plan",
 )
 
 _lib = None
@@ -56,6 +66,7 @@ def lib():
         L.rt_debug_trace_rays.argtypes = [vp, C.c_int32, fp, fp, C.c_int64, C.POINTER(C.c_int32), fp]
         L.rt_debug_block_costs.argtypes = [vp, C.POINTER(C.c_uint32), C.c_int32]
         L.rt_debug_wave_timeline.argtypes = [vp, C.POINTER(C.c_uint64)]
+        L.rt_debug_band_copy_plan.argtypes = [C.c_int32] * 9 + [C.POINTER(abi.RtBandCopy), C.c_int32]
         L.rt_register_output.argtypes = [vp, vp, C.c_size_t]
         L.rt_unregister_output.argtypes = [vp]
         L.rt_triangle_compute_normal.argtypes = [C.POINTER(abi.RtTriangle)]
@@ -78,6 +89,16 @@ def _check(rc):
 
 def _fp(a):
     return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def band_copy_plan(num_devices, k, device_band_rows, width, height, elem_bytes, dev_to_dev, peer_ok, same_device):
+    """The copies that deliver device k's bands of a multi-device context (rt_debug_band_copy_plan): list of dicts."""
+    n = _check(lib().rt_debug_band_copy_plan(num_devices, k, device_band_rows, width, height, elem_bytes, int(dev_to_dev),
+                                             int(peer_ok), int(same_device), None, 0))
+    buf = (abi.RtBandCopy * max(n, 1))()
+    _check(lib().rt_debug_band_copy_plan(num_devices, k, device_band_rows, width, height, elem_bytes, int(dev_to_dev),
+                                         int(peer_ok), int(same_device), buf, n))
+    return [{f: int(getattr(buf[i], f)) for f, _ in abi.RtBandCopy._fields_ if f != "reserved"} for i in range(n)]
 
 
 def selftest_rcp():
