@@ -101,6 +101,8 @@ def main():
                     help="ONE process renders rank r's bands of an N-rank split of the frame and goes through the whole N > 1 step "
                          "(two contexts on two streams, RCCL gather, the root's de-interleave over N stripes): what one rank of the "
                          "N-GPU job costs per step on the GPU and on the host (enqueue time), measured on a one-GPU box")
+    ap.add_argument("--contexts", type=int, default=2,
+                    help="N > 1: contexts (and render streams) a rank cycles through, i.e. frames in flight on its GPU")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 flow on a box with fewer GPUs than ranks (bands travel via host memory)")
     args = ap.parse_args()
@@ -171,16 +173,17 @@ def main():
     # (tools/band_pipeline.py): 2048 rows 1.97 -> 1.72 ms per frame, 1024 rows 1.04 -> 0.90, 512 rows 0.63 -> 0.63.
     pipelined = collective and args.backend == "nccl"
     if pipelined:
-        render_streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
-        tracers = [tracer, rt.RayTracer(cfg, scene)]
-        stripes = [stripe, torch.zeros_like(stripe)]
-        rendered = [torch.cuda.Event(), torch.cuda.Event()]     # stripe i holds a finished frame
-        consumed = [None, None]                                 # the gather that read stripe i has finished
+        M = max(1, args.contexts)
+        render_streams = [torch.cuda.Stream(device=dev) for _ in range(M)]
+        tracers = [tracer] + [rt.RayTracer(cfg, scene) for _ in range(M - 1)]
+        stripes = [stripe] + [torch.zeros_like(stripe) for _ in range(M - 1)]
+        rendered = [torch.cuda.Event() for _ in range(M)]       # stripe i holds a finished frame
+        consumed = [None] * M                                   # the gather that read stripe i has finished
     state = {"k": 0}
 
     def step(ev=None):
         if pipelined:
-            i = state["k"] % 2
+            i = state["k"] % len(tracers)
             state["k"] += 1
             cur = torch.cuda.current_stream()
             render_stream = render_streams[i]

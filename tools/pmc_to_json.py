@@ -50,7 +50,7 @@ def main():
     trace = {}
     for k, v in per.items():
         lps = len(v) / float(W + K)               # launches per step
-        if lps < 0.99 or abs(lps - round(lps)) > 1e-9:
+        if lps < 0.9 or abs(lps - round(lps)) > 0.05:       # (a kernel that skips a context's first frame still counts as once per step)
             trace[k] = {"launches": len(v), "launches_per_step": None, "avg_ns": sum(v) / len(v)}
             continue
         lps = int(round(lps))
