@@ -86,7 +86,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20,
                     help="untimed frames first (the device needs ~15 frames / 50 ms of load to reach its clocks, profiles/r02_wave_timeline.txt)")
     ap.add_argument("--workload", default="headline", choices=list(WORKLOADS))
-    ap.add_argument("--band-rows", type=int, default=32)
+    ap.add_argument("--band-rows", type=int, default=16,
+                    help="rows per band of the interleaved partition (N > 1).  16: the shares of the ranks of 8 cost the same within 1 %% "
+                         "(32: the dearest rank of 8 took 10 %% longer than the cheapest, profiles/r03_emulated_ranks.txt)")
     ap.add_argument("--cpu-sample-pixels", type=int, default=0, help="0 = auto (about 10-30 s of CPU work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-brute-force", action="store_true", help="skip the cull-off comparison leg (N=1 only)")
@@ -176,29 +178,35 @@ def main():
         M = max(1, args.contexts)
         render_streams = [torch.cuda.Stream(device=dev) for _ in range(M)]
         tracers = [tracer] + [rt.RayTracer(cfg, scene) for _ in range(M - 1)]
-        stripes = [stripe] + [torch.zeros_like(stripe) for _ in range(M - 1)]
-        rendered = [torch.cuda.Event() for _ in range(M)]       # stripe i holds a finished frame
-        consumed = [None] * M                                   # the gather that read stripe i has finished
+        # two stripe buffers per context: the render of frame k + M (same context) does not wait for the gather of frame k
+        # (with one, the chain render -> gather -> next render of that context set the period: kernel trace of an emulated
+        # rank, 0.4526 ms/step of which 0.15 ms were that wait)
+        NS_ = M * max(1, int(os.environ.get("BENCH_STRIPES_PER_CONTEXT", "2")))
+        stripes = [stripe] + [torch.zeros_like(stripe) for _ in range(NS_ - 1)]
+        rendered = [torch.cuda.Event() for _ in range(NS_)]      # stripe j holds a finished frame
+        consumed = [torch.cuda.Event() for _ in range(NS_)]      # the gather that read stripe j has finished
+        consumed_valid = [False] * NS_
     state = {"k": 0}
 
     def step(ev=None):
         if pipelined:
             i = state["k"] % len(tracers)
+            j = state["k"] % len(stripes)
             state["k"] += 1
             cur = torch.cuda.current_stream()
             render_stream = render_streams[i]
-            if consumed[i] is not None:
-                render_stream.wait_event(consumed[i])
+            if consumed_valid[j]:
+                render_stream.wait_event(consumed[j])
             if ev:
                 ev[0].record(render_stream)
-            tracers[i].render_device(rot, cam, light, focal, stripes[i].data_ptr(), None, render_stream.cuda_stream)
+            tracers[i].render_device(rot, cam, light, focal, stripes[j].data_ptr(), None, render_stream.cuda_stream)
             if ev:
                 ev[1].record(render_stream)
-            rendered[i].record(render_stream)
-            cur.wait_event(rendered[i])
-            bands.gather_frame(stripes[i], part_world, part_rank, band_rows, gathered, frame_pad, force=True, height=H, emulate=emu is not None)
-            consumed[i] = torch.cuda.Event()
-            consumed[i].record(cur)
+            rendered[j].record(render_stream)
+            cur.wait_event(rendered[j])
+            bands.gather_frame(stripes[j], part_world, part_rank, band_rows, gathered, frame_pad, force=True, height=H, emulate=emu is not None)
+            consumed[j].record(cur)
+            consumed_valid[j] = True
             return
         # the HIP kernel, enqueued on torch's current stream through the C ABI
         if ev:
@@ -232,11 +240,16 @@ def main():
         work = {k: 0 for k, _ in abi.RtWork._fields_}
         executed = {}
     else:
-        work = tracer.count_work(rot, cam, light, focal)
+        # (N > 1: every rank counts the WHOLE frame — no reduction needed, and the 0.3 s of load bring the device to its
+        # clocks before the short warm-up of a 0.45 ms step)
+        counter = tracer if not collective else rt.RayTracer(abi.make_config(device=local_rank, **wl), scene)
+        work = counter.count_work(rot, cam, light, focal)
         try:
-            executed = tracer.count_executed(rot, cam, light, focal)
+            executed = counter.count_executed(rot, cam, light, focal)
         except rt.RtError:
             executed = {}
+        if counter is not tracer:
+            counter.close()
 
     for _ in range(args.warmup):
         step()
@@ -245,9 +258,16 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(ev[k])
-    host_enqueue_s = time.perf_counter() - t0      # the host's share: every step enqueued, nothing waited for yet
     sync()
     elapsed = time.perf_counter() - t0
+    # the host's share of a step: a short burst enqueued into an EMPTY queue and not waited for (in the timed loop the
+    # host runs ahead until the queue is full and then waits for the GPU, which says nothing about its own cost)
+    burst = min(16, args.steps)
+    t1 = time.perf_counter()
+    for _ in range(burst):
+        step()
+    host_enqueue_s = (time.perf_counter() - t1) / burst * args.steps
+    sync()
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
     keys, xkeys = list(work), list(executed)
@@ -256,9 +276,7 @@ def main():
     if collective:
         mx = stats[:2].clone()
         reduce_(mx, dist.ReduceOp.MAX)
-        sm = stats[2:].clone()
-        reduce_(sm, dist.ReduceOp.SUM)
-        stats = torch.cat([mx, sm])
+        stats = torch.cat([mx, stats[2:]])          # the work counters are whole-frame counts on every rank
     stats = stats.cpu().numpy()
     elapsed, kernel_ms = float(stats[0]), float(stats[1])
     total_work = {k: int(round(v)) for k, v in zip(keys, stats[2:2 + len(keys)])}
@@ -281,7 +299,7 @@ def main():
     flops = (total_work["closest_tri_tests"] + total_work["shadow_tri_tests"]) * FLOP_PER_TRI_TEST + \
             (total_work["closest_sphere_tests"] + total_work["shadow_sphere_tests"]) * FLOP_PER_SPHERE_TEST
     # per launch = per rank: every rank runs the same kernel on 1/world of the frame
-    flops_per_launch = flops if emu else flops / world
+    flops_per_launch = flops / part_world
     achieved_tflops = flops_per_launch / (kernel_ms * 1e-3) / 1e12
     # algorithmic HBM bytes per launch: the rank's share of the ARGB frame + the scene once (workgroups re-read it from L2)
     hbm_bytes_per_launch = W * rows * 4 + len(scene) * 80

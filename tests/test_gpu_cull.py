@@ -131,3 +131,26 @@ def test_random_scenes_all_paths_agree(seed):
     assert bad.size == 0, "cull changed %d pixels, first at %s" % (len(bad), bad[0])
     assert np.array_equal(f0.view(np.uint32), f2.view(np.uint32))
     assert (a0 != 0xFF000000).mean() > 0.005
+
+
+@pytest.mark.parametrize("aa,S", [((4, 2), 64), ((2, 2), 64), ((2, 2), 16), ((2, 2), 10)])
+def test_specialised_instantiations_equal_the_generic_one(aa, S, scene, oracle):
+    """The wave kernel is compiled once more for BASELINE.json's (AA grid, sample count) pairs with those as constants
+    (rt_kernel_wave.hip); UOB_RT_NO_SPECIALISE=1 (read by rt_init) forces the generic instantiation: identical bits, two
+    views, and both equal the CPU oracle on a pixel sample."""
+    import os
+    kw = dict(width=384, height=216, aa_x=aa[0], aa_y=aa[1], shadow_samples=S)
+    for yaw, pitch, cam in CAMS[:2]:
+        rot = rt.rotation_matrix(yaw, pitch)
+        a0, f0 = _render(kw, 0, scene, rot, cam, LIGHTS[1])
+        os.environ["UOB_RT_NO_SPECIALISE"] = "1"
+        try:
+            a1, f1 = _render(kw, 0, scene, rot, cam, LIGHTS[1])
+        finally:
+            del os.environ["UOB_RT_NO_SPECIALISE"]
+        assert np.array_equal(a0, a1) and np.array_equal(f0.view(np.uint32), f1.view(np.uint32))
+        pix = np.sort(np.random.default_rng(S).choice(384 * 216, 3000, replace=False)).astype(np.int32)
+        v, n, c = scene.packed()
+        cfg = abi.make_config(**kw)
+        want, _ = oracle.render(cfg, v, n, c, rot, cam, LIGHTS[1], focal_for(cfg), pix=pix, nthreads=8)
+        assert np.array_equal(a0.ravel()[pix], want)

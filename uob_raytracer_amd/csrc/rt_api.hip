@@ -78,6 +78,8 @@ struct Tuning {
   int heavy_factor4 = 8;      // UOB_RT_HEAVY_FACTOR4: a job is expensive above this / 4 times the average cost
   bool plain_order = false;   // RT_FLAG_PLAIN_ORDER or UOB_RT_PLAIN_ORDER
   bool full_grid = false;     // UOB_RT_FULL_GRID: a rank of a multi-GPU job fills every wave slot too
+  bool no_specialise = false; // UOB_RT_NO_SPECIALISE: the generic wave-kernel instantiation also where a specialised one exists
+  int grid_per_cu = 0;        // UOB_RT_GRID_PER_CU: workgroups per CU of the wave kernel's persistent grid (experiments)
   bool phase_profile = false; // UOB_RT_PHASE_PROFILE: rt_count_executed returns s_memtime shares per phase
   int split_listed = 0;       // UOB_RT_SPLIT_LISTED=1: last frame's expensive jobs are handed out one task at a time
   bool timeline = false;      // UOB_RT_TIMELINE: the wave kernel records when its waves start and end (rt_debug_wave_timeline)
@@ -172,6 +174,8 @@ static Tuning read_tuning(const rt_config& cfg) {
   if (const char* e = getenv("UOB_RT_HEAVY_FACTOR4")) { const int v = atoi(e); if (v >= 1 && v <= 4096) t.heavy_factor4 = v; }
   t.plain_order = (cfg.flags & RT_FLAG_PLAIN_ORDER) != 0 || getenv("UOB_RT_PLAIN_ORDER") != nullptr;
   t.full_grid = getenv("UOB_RT_FULL_GRID") != nullptr;
+  t.no_specialise = getenv("UOB_RT_NO_SPECIALISE") != nullptr;
+  if (const char* e = getenv("UOB_RT_GRID_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 8) t.grid_per_cu = v; }
   t.phase_profile = getenv("UOB_RT_PHASE_PROFILE") != nullptr;
   t.timeline = getenv("UOB_RT_TIMELINE") != nullptr;
   if (const char* e = getenv("UOB_RT_SPLIT_LISTED")) { const int v = atoi(e); if (v == 0 || v == 1) t.split_listed = v; }
@@ -520,7 +524,7 @@ static void fill_params(const rt_ctx* c, const float rot[12], const float cam[3]
     P->aax_magic = (65536 + g.aa_x - 1) / g.aa_x;
     // workgroups the chip holds at once; a rank of a multi-GPU job leaves one slot per CU free (registers and LDS
     // for a workgroup of a collective's kernels), so that the gather of the previous frame can run beside it
-    const int per_cu = wave_blocks_per_cu(g.band_count > 1 && !c->tune.full_grid);
+    const int per_cu = c->tune.grid_per_cu ? c->tune.grid_per_cu : wave_blocks_per_cu(g.band_count > 1 && !c->tune.full_grid);
     P->wave_blocks = c->cus * per_cu;
     const long waves = (long)P->wave_blocks * 4;
     int jt = wave_aa ? 64 / pt : 1;                      // tasks of a 64-pixel job (aa for the power-of-two grids)
@@ -545,6 +549,7 @@ static void fill_params(const rt_ctx* c, const float rot[12], const float cam[3]
     // (measured on one rank's 512 rows of the headline frame, whose longest jobs last 0.5 of its 0.57 ms: 0.570 ms with,
     // 0.566 without — the span is set by the work per wave and the ~60 us tail, not by the longest job; off unless asked for)
     P->split_listed = c->tune.split_listed == 1 && jt > 1 ? 1 : 0;
+    P->no_specialise = c->tune.no_specialise ? 1 : 0;
     P->job_hx = 0.5f * (float)(job_pixels * g.aa_x - 1);
     P->job_hy = 0.5f * (float)(g.aa_y - 1) * P->sy;
     for (int k = 0; k < 3; ++k)

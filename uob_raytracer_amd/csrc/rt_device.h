@@ -75,6 +75,7 @@ struct FrameParams {
   int32_t aax_magic;      // ceil(65536 / aa_x): a / aa_x == (a * aax_magic) >> 16 for an AA sample index a < 4096
   int32_t job_tasks;      // wave kernel: 64-ray tasks per job (a job = job_tasks * 64 / aa consecutive pixels of a row)
   int32_t split_listed;   // wave kernel: 1 = last frame's expensive jobs are handed out one task at a time (short frames)
+  int32_t no_specialise;  // wave kernel: 1 = always the generic instantiation (UOB_RT_NO_SPECIALISE: A/B and equivalence tests)
   // wave kernel: jobs that were expensive in the previous frame of this context are handed out first (the kernel
   // ends when its last job does, so the long ones should start early); nullptr = plain order
   const unsigned int* heavy_prev;     // their job ids

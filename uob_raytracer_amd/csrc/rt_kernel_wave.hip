@@ -225,6 +225,33 @@ __device__ __forceinline__ Count2 wave_unshadowed_pair(const FrameParams& P, con
 
 }  // namespace
 
+// Job-level ("cold") kernel arguments.  FrameParams arrives by value in the kernarg segment; every field the compiler sees
+// used anywhere in the kernel is loaded once in the prologue and kept in a scalar register for the whole kernel — ~95 of the
+// 102 a wave has, so that half of them were spilled to VGPR lanes and came back through v_readlane (a VALU slot each) at
+// every use.  The fields below are touched a few times per JOB (queue, expensive-job list, row arithmetic, the job's
+// bundle box, the store): they are read through a pointer to the kernarg segment the optimiser cannot see through, i.e. by
+// an s_load at the point of use (scalar cache hit) instead of living in a register.
+typedef const __attribute__((address_space(4))) FrameParams* KernargParams;
+__device__ __forceinline__ KernargParams cold(const FrameParams&) {
+  unsigned long long a = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(a));
+  return (KernargParams)a;
+}
+__device__ __forceinline__ int band_global_row_cold(const FrameParams& P, int lr) {
+  KernargParams K = cold(P);
+  const int br = K->band_rows;
+  const int q = (int)div_magic((uint32_t)lr, K->band_rows_magic);
+  return (q * K->band_count + K->band_index) * br + (lr - q * br);
+}
+#ifndef RT_COLD_PARAMS
+#define RT_COLD_PARAMS 1
+#endif
+#if RT_COLD_PARAMS
+#define PC(field) (cold(P)->field)
+#else
+#define PC(field) (P.field)
+#endif
+
 // Persistent waves: the grid is what fits the chip at once (CUs x RT_MIN_WAVES workgroups of 4 waves); each
 // wave pulls 64-pixel segments (jobs) from an atomic counter until none is left, so a wave slot is never idle
 // while work remains.  (With one workgroup per 4 segments the cost spread between fully lit and penumbra
@@ -254,7 +281,11 @@ __host__ __device__ constexpr int wave_fixed_lds_float4() {
 }
 
 // MULTI: more than 64 shadow samples per surface point, worked off in passes of 64 sample lanes
-template <bool CULL, bool COUNT, bool PROF = false, int STRIDE = 0, bool MULTI = false>
+// AA_X, AA_Y, SS > 0: the AA grid and the sample count are compile-time constants ("specialise on (AA,
+// samples)"): the lane <-> (pixel, AA sample) arithmetic becomes shifts, the 64 adds of direct_light's sum and the AA sum
+// straight-line code, and a dozen wave-uniform conditions (and the scalar registers they were spilled from) disappear.
+// Same operations on the same values: the frame is bit-identical to the generic instantiation's (tests/test_gpu_cull.py).
+template <bool CULL, bool COUNT, bool PROF = false, int STRIDE = 0, bool MULTI = false, int AA_X = 0, int AA_Y = 0, int SS = 0>
 // 5 waves per SIMD (<= 96 VGPRs; what spills is written once per wave, outside the loops): the kernel is bound by
 // instruction issue and needs the waves — 5 per SIMD measured 3.76 ms against 4.10 ms at 4 (128 VGPRs)
 #ifndef RT_MIN_WAVES
@@ -298,14 +329,18 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
   const WaveLds L = wave_lds(reinterpret_cast<char*>(scbase + 4 * sst) + wave * wave_lds_bytes(CULL), CULL);
 
   const LdsScene S = lds_scene(lds, n, st);
-  const int aa = P.aa_x * P.aa_y;                                     // a power of two <= 64 (supports())
+  const int aa_x = AA_X ? AA_X : P.aa_x, aa_y = AA_Y ? AA_Y : P.aa_y;
+  const float sy = (AA_X && AA_Y) ? (float)AA_X / (float)AA_Y : P.sy;
+  const int aa = aa_x * aa_y;                                         // 1..64 AA samples per pixel (supports())
   const int PT = 64 / aa;                                             // pixels per task (lanes >= PT * aa idle)
   const int GP = PT < kRngPixels ? PT : kRngPixels;                   // pixels per RNG group
   const int gp_magic = (65536 + GP - 1) / GP;                         // q / GP == (q * gp_magic) >> 16 for q < 64
   const f3 light = mk(P.light[0], P.light[1], P.light[2]);
   const float hbox = P.hbox;                                          // |crush()| <= range/2, :51
   const unsigned long long tri_lanes = ns == 64 ? ~0ull : ((1ull << ns) - 1ull);
-  const int NS = P.S;                                                 // shadow samples = sample lanes, <= 64
+  const int NS = SS ? SS : P.S;                                       // shadow samples = sample lanes, <= 64
+  const float inv_S = SS ? ((SS & (SS - 1)) == 0 ? 1.0f / (float)(SS ? SS : 1) : 0.0f) : P.inv_S;
+  const float inv_aa = (AA_X && AA_Y) ? (((AA_X * AA_Y) & (AA_X * AA_Y - 1)) == 0 ? 1.0f / (float)(AA_X * AA_Y ? AA_X * AA_Y : 1) : 0.0f) : P.inv_aa;
   const int n_pass = MULTI ? (NS + 63) >> 6 : 1;                      // passes of 64 sample lanes
   const unsigned long long active = NS >= 64 ? ~0ull : ((1ull << NS) - 1ull);     // sample lanes of a full pass
 
@@ -330,7 +365,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
   // are pulled (phase A, second set of heads) before the plain sequence (phase B, which skips them by their flag).
   // (Handing the expensive jobs out one TASK at a time, to different waves, was built and measured: no gain at 512 rows
   // per rank, 2 % lost on the whole frame.)
-  const bool lpt = !COUNT && !PROF && P.heavy_new != nullptr;
+  const bool lpt = !COUNT && !PROF && PC(heavy_new) != nullptr;
   unsigned int n_heavy = 0u;
   unsigned long long heavy_thr = ~0ull;
   // this wave's sum of job costs and job count live in the padding words of its RNG scratch (kept in registers
@@ -338,14 +373,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
   unsigned long long* const cost_acc = reinterpret_cast<unsigned long long*>(L.rng + 256);
   if (lpt && lane == 0) { cost_acc[0] = 0ull; cost_acc[1] = 0ull; }
   if (lpt) {
-    n_heavy = P.heavy_prev_state[0] < (unsigned int)P.heavy_cap ? P.heavy_prev_state[0] : (unsigned int)P.heavy_cap;
-    const unsigned long long psum = ((unsigned long long)P.heavy_prev_state[3] << 32) | P.heavy_prev_state[2];
-    const unsigned int pjobs = P.heavy_prev_state[4];
-    if (pjobs != 0u) heavy_thr = (unsigned long long)P.heavy_factor4 * (psum / pjobs) / 4ull;    // per TASK
+    n_heavy = PC(heavy_prev_state)[0] < (unsigned int)PC(heavy_cap) ? PC(heavy_prev_state)[0] : (unsigned int)PC(heavy_cap);
+    const unsigned long long psum = ((unsigned long long)PC(heavy_prev_state)[3] << 32) | PC(heavy_prev_state)[2];
+    const unsigned int pjobs = PC(heavy_prev_state)[4];
+    if (pjobs != 0u) heavy_thr = (unsigned long long)PC(heavy_factor4) * (psum / pjobs) / 4ull;    // per TASK
   }
   // diagnostic (UOB_RT_TIMELINE): when this wave starts asking for jobs and how many it gets; kept in the padding words of
   // the second pixel's RNG scratch, not in registers
-  const bool timeline = !COUNT && !PROF && P.counters != nullptr;
+  const bool timeline = !COUNT && !PROF && PC(counters) != nullptr;
   unsigned long long* const tls = reinterpret_cast<unsigned long long*>(L.rng + kRngStride + 256);
   if (timeline && lane == 0) { tls[0] = __builtin_amdgcn_s_memrealtime(); tls[1] = 0ull; }
   bool phase_a = n_heavy != 0u;
@@ -355,18 +390,18 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
   // never see a full hand-out (measured, ms: 1024 rows, 64-pixel jobs: 0.92 with T = 8, 1.00 with T = 1; 512 rows, 32-pixel
   // jobs: 0.570 against 0.540).
   const int grid_waves = (int)gridDim.x * kWavesPerBlock;
-  const int per_wave = P.job_tasks * PT > 32 ? 8 * grid_waves : grid_waves;
+  const int per_wave = PC(job_tasks) * PT > 32 ? 8 * grid_waves : grid_waves;
   int next_job = -1, chunk_left = 0;                    // the rest of the last hand-out, still to do
   unsigned int listed = 0u;                             // bit i: job i of the rest of the hand-out is on last frame's list
-  int chunk = P.njobs > 2 * per_wave ? RT_CHUNK : (P.njobs > per_wave ? 2 : 1);      // size of the next hand-out
+  int chunk = PC(njobs) > 2 * per_wave ? RT_CHUNK : (PC(njobs) > per_wave ? 2 : 1);      // size of the next hand-out
   for (;;) {
   int job = 0;
-  const int jt = P.job_tasks;                 // tasks of this hand-out
+  const int jt = PC(job_tasks);                 // tasks of this hand-out
   int k0 = 0, k1 = jt;                        // the tasks of the job this hand-out covers
   if (phase_a) {
-    if (lane == 0) job = (int)atomicAdd(P.job_counter + (kJobHeads + head) * kJobHeadStride, 1u);
+    if (lane == 0) job = (int)atomicAdd(PC(job_counter) + (kJobHeads + head) * kJobHeadStride, 1u);
     unsigned int unit = (unsigned int)__builtin_amdgcn_readfirstlane(job) * kJobHeads + (unsigned int)head;
-    if (P.split_listed) {
+    if (PC(split_listed)) {
       // UOB_RT_SPLIT_LISTED=1: the listed jobs go out one TASK at a time (unit u = task u / n of listed job u % n, all
       // first tasks before all second ones) — for frames so short that one job's 64 undecided surface points per task
       // (25x an ordinary task, profiles/r02_wave_timeline.txt) could be the critical path.  Measured: they are not.
@@ -374,13 +409,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
       if (q >= (unsigned int)jt) { phase_a = false; continue; }
       unit -= q * n_heavy; k0 = (int)q; k1 = k0 + 1;
     } else if (unit >= n_heavy) { phase_a = false; continue; }
-    job = (int)P.heavy_prev[unit];
-    if (job < 0 || job >= P.njobs) continue;
+    job = (int)PC(heavy_prev)[unit];
+    if (job < 0 || job >= PC(njobs)) continue;
   } else {
     if (chunk_left > 0) {
       job = next_job; next_job += kJobHeads; --chunk_left; listed >>= 1;
     } else {
-      if (lane == 0) job = (int)atomicAdd(P.job_counter + head * kJobHeadStride, (unsigned int)chunk);
+      if (lane == 0) job = (int)atomicAdd(PC(job_counter) + head * kJobHeadStride, (unsigned int)chunk);
       job = __builtin_amdgcn_readfirstlane(job) * kJobHeads + head;
       next_job = job + kJobHeads; chunk_left = chunk - 1;
       // which jobs of this hand-out are on last frame's list (phase A takes care of those): ONE load for the hand-out,
@@ -388,19 +423,19 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
       listed = 0u;
       if (n_heavy != 0u) {
         const int jl = job + lane * kJobHeads;
-        listed = (unsigned int)ballot(lane <= chunk_left && jl < P.njobs && P.heavy_flags[jl] >= P.heavy_gen);
+        listed = (unsigned int)ballot(lane <= chunk_left && jl < PC(njobs) && PC(heavy_flags)[jl] >= PC(heavy_gen));
       }
       // what this head has left decides the next hand-out
-      const int left = P.njobs - next_job;
+      const int left = PC(njobs) - next_job;
       chunk = left > 2 * per_wave ? RT_CHUNK : (left > per_wave ? 2 : 1);
     }
-    if (job >= P.njobs) {
+    if (job >= PC(njobs)) {
       chunk_left = 0;
       bool found = false;
       while (!found && ++heads_done < kJobHeads) {
         head = head + 1 == kJobHeads ? 0 : head + 1;
-        const unsigned int at = __hip_atomic_load(P.job_counter + head * kJobHeadStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        found = (long long)at * kJobHeads + head < (long long)P.njobs;
+        const unsigned int at = __hip_atomic_load(PC(job_counter) + head * kJobHeadStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        found = (long long)at * kJobHeads + head < (long long)PC(njobs);
       }
       if (!found) break;
       continue;
@@ -414,12 +449,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
   // Rows are handed out from the middle of the rank's rows outwards: segments differ 10x in cost, and the kernel
   // ends when the last job does, so the last jobs should be cheap ones — the top and bottom rows of a view
   // usually are (background, plain walls).
-  const int jrow = (int)div_magic((uint32_t)job, P.nseg_magic);
-  const int mid = (P.owned_rows + 1) >> 1;
+  const int jrow = (int)div_magic((uint32_t)job, PC(nseg_magic));
+  const int mid = (PC(owned_rows) + 1) >> 1;
   const int lr = (jrow & 1) ? mid + (jrow >> 1) : mid - 1 - (jrow >> 1);
   const int JP = jt * PT;                          // pixels of this hand-out
-  const int x0 = (job - jrow * P.nseg) * JP;
-  const int y = band_global_row(P, lr);
+  const int x0 = (job - jrow * PC(nseg)) * JP;
+  const int y = band_global_row_cold(P, lr);
   f3 outc = mk(0.f, 0.f, 0.f);
   // Triangles a primary ray of this job may hit, bounded once for the job's 64 x 1 pixels (all AA samples): the
   // rays leave the camera through a sub-pixel rectangle, see primary_clear.  (Per task the rectangle is 8x
@@ -428,13 +463,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
   bool sph_job = P.nsph > 0;
   if (CULL) {
     const int lnJ = opaque(lane);
-    const float Xlo = (float)(x0 * P.aa_x) - P.half_wx;
-    const float Ylo = ((float)(y * P.aa_y) - P.half_hy) * P.sy;
+    const float Xlo = (float)(x0 * aa_x) - P.half_wx;
+    const float Ylo = ((float)(y * aa_y) - P.half_hy) * sy;
     // a hand-out narrower than a job (none at present) would only make the box generous
-    const f3 wc = mk(Xlo + P.job_hx, Ylo + P.job_hy, P.focal);
+    const f3 wc = mk(Xlo + PC(job_hx), Ylo + PC(job_hy), P.focal);
     const f3 duc = mk(P.rot[0] * wc.x + P.rot[1] * wc.y + P.rzf[0], P.rot[4] * wc.x + P.rot[5] * wc.y + P.rzf[1],
                       P.rot[8] * wc.x + P.rot[9] * wc.y + P.rzf[2]);
-    const f3 eu = mk(P.job_eu[0], P.job_eu[1], P.job_eu[2]);
+    const f3 eu = mk(PC(job_eu[0]), PC(job_eu[1]), PC(job_eu[2]));
     const float dumax = fmaxf(fmaxf(fabsf(duc.x) + eu.x, fabsf(duc.y) + eu.y), fabsf(duc.z) + eu.z);
     const int ti = lnJ < n ? lnJ : 0;
     const float4 c4 = S.c[ti];
@@ -449,13 +484,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
   for (int k = k0; k < k1; ++k) {
     const int lnA = opaque(lane);
     // ---- phase 1: 64 primary rays, lnA = (pixel, AA sample) -----------------------------------------
-    const int pA = (lnA * P.aa_magic) >> 16;   // lnA / aa
+    const int pA = (AA_X && AA_Y) ? lnA / (AA_X * AA_Y ? AA_X * AA_Y : 1) : (lnA * P.aa_magic) >> 16;   // lnA / aa
     const int pj = k * PT + pA;                // pixel of this lnA within the job
     const int a = lnA - pA * aa;               // AA sample index dy*rx+dx, kernels.cl:395
     const int x = x0 + pj;
     const bool valid = x < P.W && pA < PT;
-    const int ay = (a * P.aax_magic) >> 16;        // a / aa_x (a < 256)
-    Ray ray = primary_ray(P, x, y, a - ay * P.aa_x, ay);
+    const int ay = AA_X ? a / (AA_X ? AA_X : 1) : (a * P.aax_magic) >> 16;        // a / aa_x (a < 256)
+    Ray ray = primary_ray(P, x, y, a - ay * aa_x, ay, aa_x, aa_y, sy);
     bool lit = false, secondary = false;
     // triangles a primary ray of this job may hit (read back through readfirstlane: the set is the same in every lane, and
     // the loop over it then runs on the scalar unit)
@@ -704,14 +739,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
         for (int i = 0; i < NS; ++i) if (i < unshadowed) total += term;
       }
       if (lit) {
-        const float l = 0.5f + div_count(total, NS, P.inv_S);
+        const float l = 0.5f + div_count(total, NS, inv_S);
         if (secondary) { const float kk = 0.9f * l; contrib = mk(kk * ray.col.x, kk * ray.col.y, kk * ray.col.z); }
         else contrib = mk(ray.col.x * l, ray.col.y * l, ray.col.z * l);
       }
     }
     // sum the AA rays of each pixel in index order (final_color_total +=, :415-425); a ray without a
     // contribution adds +0, which leaves the running sum unchanged bit for bit
-    const f3 acc = aa_sum(contrib, aa, ((lnD * P.aa_magic) >> 16) * aa);
+    const f3 acc = aa_sum(contrib, aa, ((AA_X && AA_Y) ? lnD / (AA_X * AA_Y ? AA_X * AA_Y : 1) : (lnD * P.aa_magic) >> 16) * aa);
     // pixel pj's sum lives in lanes [pj*aa, pj*aa+aa); hand it to output lnD (k*PT + pj)
     {
       const int rel = lnD - k * PT;
@@ -724,40 +759,40 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
   // ---- store: the job's consecutive pixels, one coalesced access per wave ------------------------------
   const int x = x0 + lane;
   if (!COUNT && !PROF && lane >= k0 * PT && lane < k1 * PT && x < P.W) {
-    const f3 c = mk(div_count(outc.x, aa, P.inv_aa), div_count(outc.y, aa, P.inv_aa), div_count(outc.z, aa, P.inv_aa));
-    const size_t o = (size_t)(P.out_global ? y : lr) * P.W + x;
-    P.out_argb[o] = pack_argb(c);
-    if (P.out_rgb) P.out_rgb[o] = make_float4(c.x, c.y, c.z, 1.0f);
+    const f3 c = mk(div_count(outc.x, aa, inv_aa), div_count(outc.y, aa, inv_aa), div_count(outc.z, aa, inv_aa));
+    const size_t o = (size_t)(PC(out_global) ? y : lr) * P.W + x;
+    PC(out_argb)[o] = pack_argb(c);
+    if (PC(out_rgb)) PC(out_rgb)[o] = make_float4(c.x, c.y, c.z, 1.0f);
   }
   if (lpt) {
     const unsigned long long cost = __builtin_amdgcn_s_memtime() - job_t0;
     if (lane == 0) { cost_acc[0] += cost; cost_acc[1] += (unsigned long long)(k1 - k0); }
     if (cost > heavy_thr * (unsigned long long)(k1 - k0) && lane == 0) {
       // listed once per frame, by whichever wave finds one of its tasks expensive first
-      const unsigned int was = atomicMax(P.heavy_flags + job, P.heavy_gen + 1u);
-      if (was < P.heavy_gen + 1u) {
-        const unsigned int at = atomicAdd(P.heavy_new_state, 1u);
-        if (at < (unsigned int)P.heavy_cap) P.heavy_new[at] = (unsigned int)job;
-        else atomicExch(P.heavy_flags + job, was);         // list full: not listed after all
+      const unsigned int was = atomicMax(PC(heavy_flags) + job, PC(heavy_gen) + 1u);
+      if (was < PC(heavy_gen) + 1u) {
+        const unsigned int at = atomicAdd(PC(heavy_new_state), 1u);
+        if (at < (unsigned int)PC(heavy_cap)) PC(heavy_new)[at] = (unsigned int)job;
+        else atomicExch(PC(heavy_flags) + job, was);         // list full: not listed after all
       }
     }
   }
   }                                          // ---- end of the job loop ---------------------------------------
   if (lpt && lane == 0) {
-    atomicAdd(reinterpret_cast<unsigned long long*>(P.heavy_new_state + 2), cost_acc[0]);
-    atomicAdd(P.heavy_new_state + 4, (unsigned int)cost_acc[1]);
+    atomicAdd(reinterpret_cast<unsigned long long*>(PC(heavy_new_state) + 2), cost_acc[0]);
+    atomicAdd(PC(heavy_new_state) + 4, (unsigned int)cost_acc[1]);
   }
   if (timeline && lane == 0) {
     const unsigned long long t1 = __builtin_amdgcn_s_memrealtime(), t0 = tls[0];
-    unsigned long long* const rec = P.counters + 3 * (size_t)(blockIdx.x * kWavesPerBlock + wave);   // one record per wave
+    unsigned long long* const rec = PC(counters) + 3 * (size_t)(blockIdx.x * kWavesPerBlock + wave);   // one record per wave
     rec[0] = t0; rec[1] = t1; rec[2] = tls[1] | ((unsigned long long)n_heavy << 32);   // (+ the length of the list this frame started from)
   }
   if (PROF) {
-    if (lane == 0) for (int q = 0; q < 8; ++q) atomicAdd(&P.counters[q], prof[q]);
+    if (lane == 0) for (int q = 0; q < 8; ++q) atomicAdd(&PC(counters)[q], prof[q]);
     return;
   }
   if (COUNT) {                               // wave-uniform counters: lane 0 publishes them
-    if (lane == 0) for (int q = 0; q < 8; ++q) if (xw.v[q]) atomicAdd(&P.counters[q], xw.v[q]);
+    if (lane == 0) for (int q = 0; q < 8; ++q) if (xw.v[q]) atomicAdd(&PC(counters)[q], xw.v[q]);
   }
 }
 
@@ -768,6 +803,11 @@ template __global__ void rt_draw_wave<true, true>(const FrameParams);
 template __global__ void rt_draw_wave<true, false, true>(const FrameParams);
 template __global__ void rt_draw_wave<true, false, false, 32>(const FrameParams);
 template __global__ void rt_draw_wave<true, false, false, 0, true>(const FrameParams);
+// specialised on (AA grid, samples): BASELINE.json's configurations and the reference as shipped
+template __global__ void rt_draw_wave<true, false, false, 32, false, 4, 2, 64>(const FrameParams);   // the headline frame
+template __global__ void rt_draw_wave<true, false, false, 32, false, 2, 2, 64>(const FrameParams);
+template __global__ void rt_draw_wave<true, false, false, 32, false, 2, 2, 16>(const FrameParams);   // configs[1]
+template __global__ void rt_draw_wave<true, false, false, 32, false, 2, 2, 10>(const FrameParams);   // the reference's own constants, configs[2]
 template __global__ void rt_draw_wave<false, false, false, 0, true>(const FrameParams);
 
 bool wave_kernel_supports(const FrameParams& P) {
@@ -813,7 +853,12 @@ void launch_wave(const FrameParams& P, bool cull, bool count, hipStream_t stream
     if (cull) hipLaunchKernelGGL((rt_draw_wave<true, false, false, 0, true>), grid, block, lds_bytes, stream, P);
     else hipLaunchKernelGGL((rt_draw_wave<false, false, false, 0, true>), grid, block, lds_bytes, stream, P);
   } else {
-    if (cull && P.n <= 32) hipLaunchKernelGGL((rt_draw_wave<true, false, false, 32>), grid, block, 0, stream, P);
+    const bool spec = cull && P.n <= 32 && !P.no_specialise;
+    if (spec && P.aa_x == 4 && P.aa_y == 2 && P.S == 64) hipLaunchKernelGGL((rt_draw_wave<true, false, false, 32, false, 4, 2, 64>), grid, block, 0, stream, P);
+    else if (spec && P.aa_x == 2 && P.aa_y == 2 && P.S == 64) hipLaunchKernelGGL((rt_draw_wave<true, false, false, 32, false, 2, 2, 64>), grid, block, 0, stream, P);
+    else if (spec && P.aa_x == 2 && P.aa_y == 2 && P.S == 16) hipLaunchKernelGGL((rt_draw_wave<true, false, false, 32, false, 2, 2, 16>), grid, block, 0, stream, P);
+    else if (spec && P.aa_x == 2 && P.aa_y == 2 && P.S == 10) hipLaunchKernelGGL((rt_draw_wave<true, false, false, 32, false, 2, 2, 10>), grid, block, 0, stream, P);
+    else if (cull && P.n <= 32) hipLaunchKernelGGL((rt_draw_wave<true, false, false, 32>), grid, block, 0, stream, P);
     else if (cull) hipLaunchKernelGGL((rt_draw_wave<true, false>), grid, block, lds_bytes, stream, P);
     else hipLaunchKernelGGL((rt_draw_wave<false, false>), grid, block, lds_bytes, stream, P);
   }

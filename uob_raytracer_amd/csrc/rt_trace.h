@@ -318,13 +318,14 @@ __device__ bool bounce_to_diffuse(const LdsScene& S, const FrameParams& P, Ray& 
 
 // Primary ray through AA sample (dx,dy) of pixel (x,y): kernels.cl:384-407.  Units are AA sub-pixels
 // along x; sy = aa_x/aa_y rescales the y pitch for non-square grids (1 for the reference's square ones).
-__device__ __forceinline__ Ray primary_ray(const FrameParams& P, int x, int y, int dx, int dy) {
+// aa_x, aa_y, sy: P.aa_x, P.aa_y, P.sy — passed separately so that a kernel specialised on the grid hands in constants
+__device__ __forceinline__ Ray primary_ray(const FrameParams& P, int x, int y, int dx, int dy, int aa_x, int aa_y, float sy) {
   // (Wf*rx)/2, (Hf*ry)/2, focal + 0 and r_k.z * d.z are frame invariants, evaluated on the host with the same operations
-  const float bx = (float)(x * P.aa_x) - P.half_wx;
-  const float by = (float)(y * P.aa_y) - P.half_hy;
+  const float bx = (float)(x * aa_x) - P.half_wx;
+  const float by = (float)(y * aa_y) - P.half_hy;
   Ray ray;
   ray.start = mk(P.cam[0], P.cam[1], P.cam[2]);
-  const float dxs = bx + (float)dx, dys = (by + (float)dy) * P.sy;
+  const float dxs = bx + (float)dx, dys = (by + (float)dy) * sy;
   // dot(r_k, d) = r_k.x*d.x + r_k.y*d.y + r_k.z*d.z, left to right
   ray.dir = normalize3(mk(P.rot[0] * dxs + P.rot[1] * dys + P.rzf[0], P.rot[4] * dxs + P.rot[5] * dys + P.rzf[1],
                           P.rot[8] * dxs + P.rot[9] * dys + P.rzf[2]));
@@ -334,6 +335,10 @@ __device__ __forceinline__ Ray primary_ray(const FrameParams& P, int x, int y, i
   ray.P = mk(0.f, 0.f, 0.f);
   ray.N = mk(0.f, 0.f, 0.f);
   return ray;
+}
+
+__device__ __forceinline__ Ray primary_ray(const FrameParams& P, int x, int y, int dx, int dy) {
+  return primary_ray(P, x, y, dx, dy, P.aa_x, P.aa_y, P.sy);
 }
 
 // color_pixel, kernels.cl:37-40
