@@ -78,6 +78,7 @@ struct Tuning {
   int heavy_factor4 = 8;      // UOB_RT_HEAVY_FACTOR4: a job is expensive above this / 4 times the average cost
   bool plain_order = false;   // RT_FLAG_PLAIN_ORDER or UOB_RT_PLAIN_ORDER
   bool full_grid = false;     // UOB_RT_FULL_GRID: a rank of a multi-GPU job fills every wave slot too
+  bool heavy_dilate = true;   // UOB_RT_HEAVY_DILATE=0: expensive jobs are listed without their row neighbours
   bool no_specialise = false; // UOB_RT_NO_SPECIALISE: the generic wave-kernel instantiation also where a specialised one exists
   int grid_per_cu = 0;        // UOB_RT_GRID_PER_CU: workgroups per CU of the wave kernel's persistent grid (experiments)
   bool phase_profile = false; // UOB_RT_PHASE_PROFILE: rt_count_executed returns s_memtime shares per phase
@@ -101,6 +102,7 @@ struct rt_ctx {
   // wave kernel: last frame's expensive jobs go first (rt_device.h FrameParams::heavy_*); two lists, used in turn
   unsigned int *d_heavy[2] = {nullptr, nullptr}, *d_heavy_flags = nullptr;
   int heavy_cap = 0, heavy_phase = 0;
+  size_t heavy_jobs_max = 0;       // entries of each of the two per-job flag arrays in d_heavy_flags
   // rt_register_output: a host range the device writes frames into directly
   char* reg_host = nullptr; char* reg_dev = nullptr; size_t reg_bytes = 0;
   bool reg_owner = false;        // this context called hipHostRegister (a child of a multi-device context only holds its device's alias)
@@ -175,6 +177,7 @@ static Tuning read_tuning(const rt_config& cfg) {
   t.plain_order = (cfg.flags & RT_FLAG_PLAIN_ORDER) != 0 || getenv("UOB_RT_PLAIN_ORDER") != nullptr;
   t.full_grid = getenv("UOB_RT_FULL_GRID") != nullptr;
   t.no_specialise = getenv("UOB_RT_NO_SPECIALISE") != nullptr;
+  if (const char* e = getenv("UOB_RT_HEAVY_DILATE")) t.heavy_dilate = atoi(e) != 0;
   if (const char* e = getenv("UOB_RT_GRID_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 8) t.grid_per_cu = v; }
   t.phase_profile = getenv("UOB_RT_PHASE_PROFILE") != nullptr;
   t.timeline = getenv("UOB_RT_TIMELINE") != nullptr;
@@ -422,12 +425,13 @@ int rt_init(const rt_config* cfg, const float* vertices4, const float* normals4,
     const int pt = (aa >= 1 && aa <= 64) ? 64 / aa : 64;
     const size_t jobs_max = (size_t)((cfg->width + pt - 1) / pt) * (size_t)(c->owned_rows > 0 ? c->owned_rows : 1);
     c->heavy_cap = (int)(jobs_max / 3 > 64 ? jobs_max / 3 : 64);
+    c->heavy_jobs_max = jobs_max;
     if (hipMemset(c->d_jobctr, 0, (2 * kJobHeads + 2) * kJobHeadStride * sizeof(unsigned int)) != hipSuccess) {
       set_error("hipMemset failed: %s", hipGetErrorString(hipGetLastError())); return fail(RT_E_DEVICE);
     }
     if (n >= 1 && n <= 64 && !c->tune.plain_order) {
       if (hipMalloc(&c->d_heavy[0], (size_t)c->heavy_cap * 4) != hipSuccess || hipMalloc(&c->d_heavy[1], (size_t)c->heavy_cap * 4) != hipSuccess ||
-          hipMalloc(&c->d_heavy_flags, jobs_max * 4) != hipSuccess || hipMemset(c->d_heavy_flags, 0, jobs_max * 4) != hipSuccess) {
+          hipMalloc(&c->d_heavy_flags, 2 * jobs_max * 4) != hipSuccess || hipMemset(c->d_heavy_flags, 0, 2 * jobs_max * 4) != hipSuccess) {
         set_error("hipMalloc failed: %s", hipGetErrorString(hipGetLastError())); return fail(RT_E_NOMEM);
       }
     }
@@ -619,9 +623,11 @@ static int launch_frame(rt_ctx* c, const float rot[12], const float cam[3], cons
       unsigned int* const st[2] = {c->d_jobctr, c->d_jobctr + (2 * kJobHeads + 1) * kJobHeadStride};
       P.heavy_prev = c->d_heavy[prev]; P.heavy_prev_state = st[prev];
       P.heavy_new = c->d_heavy[cur]; P.heavy_new_state = st[cur];
-      P.heavy_flags = c->d_heavy_flags; P.heavy_gen = ++c->heavy_gen;
+      P.heavy_flags = c->d_heavy_flags + (size_t)prev * c->heavy_jobs_max; P.heavy_flags_new = c->d_heavy_flags + (size_t)cur * c->heavy_jobs_max;
+      P.heavy_gen = ++c->heavy_gen;
       P.heavy_factor4 = c->tune.heavy_factor4;                      // expensive = more than twice the average job
       P.heavy_cap = P.njobs / 3 < c->heavy_cap ? P.njobs / 3 : c->heavy_cap;
+      P.heavy_dilate = c->tune.heavy_dilate ? 1 : 0;
       c->heavy_phase = cur;
     }
     c->timeline_valid = false;

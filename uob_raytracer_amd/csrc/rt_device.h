@@ -82,11 +82,13 @@ struct FrameParams {
   const unsigned int* heavy_prev_state;   // HeavyState of the previous frame
   unsigned int* heavy_new;            // this frame's expensive jobs, appended as they finish
   unsigned int* heavy_new_state;
-  unsigned int* heavy_flags;          // per job: the frame generation it was last listed FOR (gen = in heavy_prev;
-                                      // gen + 1 = listed again by this frame, i.e. already done)
+  const unsigned int* heavy_flags;    // per job: == heavy_gen when the job is in heavy_prev (phase A renders it; the plain sequence skips it)
+  unsigned int* heavy_flags_new;      // per job: == heavy_gen + 1 once the job is on the list this frame builds (the two arrays swap
+                                      // roles every frame; stale generations compare unequal, so neither is ever cleared)
   uint32_t heavy_gen;
   int32_t heavy_factor4;              // a job is expensive above heavy_factor4 / 4 times the average job cost
   int32_t heavy_cap;
+  int32_t heavy_dilate;               // 1: an expensive job is listed together with its two neighbours in the row
   float4* records;        // staged triangle records in HBM (8 x n float4), used when n exceeds one LDS stage
   // mesh kernel: persistent workgroups pull 16x16-pixel blocks; last frame's expensive blocks first
   const unsigned int* mesh_order;   // job order of this frame (nullptr: plain order)
