@@ -225,33 +225,6 @@ __device__ __forceinline__ Count2 wave_unshadowed_pair(const FrameParams& P, con
 
 }  // namespace
 
-// Job-level ("cold") kernel arguments.  FrameParams arrives by value in the kernarg segment; every field the compiler sees
-// used anywhere in the kernel is loaded once in the prologue and kept in a scalar register for the whole kernel — ~95 of the
-// 102 a wave has, so that half of them were spilled to VGPR lanes and came back through v_readlane (a VALU slot each) at
-// every use.  The fields below are touched a few times per JOB (queue, expensive-job list, row arithmetic, the job's
-// bundle box, the store): they are read through a pointer to the kernarg segment the optimiser cannot see through, i.e. by
-// an s_load at the point of use (scalar cache hit) instead of living in a register.
-typedef const __attribute__((address_space(4))) FrameParams* KernargParams;
-__device__ __forceinline__ KernargParams cold(const FrameParams&) {
-  unsigned long long a = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
-  asm volatile("" : "+s"(a));
-  return (KernargParams)a;
-}
-__device__ __forceinline__ int band_global_row_cold(const FrameParams& P, int lr) {
-  KernargParams K = cold(P);
-  const int br = K->band_rows;
-  const int q = (int)div_magic((uint32_t)lr, K->band_rows_magic);
-  return (q * K->band_count + K->band_index) * br + (lr - q * br);
-}
-#ifndef RT_COLD_PARAMS
-#define RT_COLD_PARAMS 1
-#endif
-#if RT_COLD_PARAMS
-#define PC(field) (cold(P)->field)
-#else
-#define PC(field) (P.field)
-#endif
-
 // Persistent waves: the grid is what fits the chip at once (CUs x RT_MIN_WAVES workgroups of 4 waves); each
 // wave pulls 64-pixel segments (jobs) from an atomic counter until none is left, so a wave slot is never idle
 // while work remains.  (With one workgroup per 4 segments the cost spread between fully lit and penumbra
