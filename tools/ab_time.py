@@ -13,10 +13,10 @@ cfg = abi.make_config(width=4096, height=4096, aa_x=4, aa_y=2, shadow_samples=64
 tr = rt.RayTracer(cfg, rt.Scene.cornell_box())
 rot, cam, light = rt.rotation_matrix(0, 0), [0, 0, -3.2], [0, -0.5, -0.7]
 buf = torch.empty((tr.rows, 4096), dtype=torch.int32, device="cuda")
-for i in range(3): tr.render_device(rot, cam, light, 17600.0, buf.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+for i in range(60): tr.render_device(rot, cam, light, 17600.0, buf.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
 torch.cuda.synchronize()
 ts = []
-for i in range(15):
+for i in range(40):
     tr.render_device(rot, cam, light, 17600.0, buf.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
     ts.append(tr.last_kernel_ms())
 ts.sort()

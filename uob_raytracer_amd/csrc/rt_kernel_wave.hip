@@ -40,6 +40,9 @@
 #ifndef RT_OPT_SPHJOB
 #define RT_OPT_SPHJOB 1
 #endif
+#ifndef RT_OPT_LIGHTSIDE
+#define RT_OPT_LIGHTSIDE 1
+#endif
 #ifndef RT_OPT_TASKSPH
 #define RT_OPT_TASKSPH 1
 #endif
@@ -573,7 +576,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
           TriLane T1;
           T1.v0 = xyz(SC.v0[(lnB < ns ? lnB : 0)]); T1.e1 = xyz(SC.e1[(lnB < ns ? lnB : 0)]); T1.e2 = xyz(SC.e2[(lnB < ns ? lnB : 0)]); T1.c = xyz(SC.c[(lnB < ns ? lnB : 0)]);
           T1.c1 = norm1(T1.c); T1.e1_1 = norm1(T1.e1); T1.e2_1 = norm1(T1.e2);
+          // The bound from the LIGHT's side (rt_wave_common.h light_bundle_bound, the mesh kernel's level 1): start and direction
+          // of a shadow ray are tied together (start = X + 1e-4 dir, X = light - dir), so the direction box counts once instead
+          // of widening both the start box and the direction box as task_bound must for an arbitrary point set: fewer
+          // survivors K for level 2.
+#if RT_OPT_LIGHTSIDE
+          const Bound tb = light_bundle_bound(T1, light, s0, es, D0, ed, hh_task, dlen_min, dlen_max, P.light_inf + dlen_max + norm1(T1.v0));
+#else
           const Bound tb = task_bound(T1, s0, D0, es, ed, hh_task, dlen_min, dlen_max);
+#endif
           K = tri_lanes & ~ballot(tb.clear);
           task_blocked = (tri_lanes & ballot(tb.all_blocked)) != 0ull;
         }
