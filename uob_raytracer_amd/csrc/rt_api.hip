@@ -233,30 +233,74 @@ static int upload_tiled_scene(rt_ctx* c, const float* v4, const float* n4, const
   }
   std::stable_sort(key.begin(), key.end(), [](const std::pair<uint32_t, int>& x, const std::pair<uint32_t, int>& y) { return x.first < y.first; });
   const int ntiles = mesh_tiles(n);
-  std::vector<float> pv((size_t)n * 12), pn((size_t)n * 4), pc((size_t)n * 4), box((size_t)ntiles * 8);
+  std::vector<float> pv((size_t)n * 12), pn((size_t)n * 4), pc((size_t)n * 4), box((size_t)ntiles * 12);
   std::vector<int> orig((size_t)n);
-  for (int t = 0; t < ntiles; ++t) { for (int k = 0; k < 3; ++k) { box[(size_t)8 * t + k] = 3.0e38f; box[(size_t)8 * t + 4 + k] = -3.0e38f; } box[(size_t)8 * t + 3] = box[(size_t)8 * t + 7] = 0.0f; }
+  for (int t = 0; t < ntiles; ++t) { for (int k = 0; k < 3; ++k) { box[(size_t)12 * t + k] = 3.0e38f; box[(size_t)12 * t + 4 + k] = -3.0e38f; } box[(size_t)12 * t + 3] = box[(size_t)12 * t + 7] = 0.0f; }
   for (int j = 0; j < n; ++j) {
     const int i = key[(size_t)j].second;
     orig[(size_t)j] = i;
     memcpy(&pv[(size_t)12 * j], v4 + (size_t)12 * i, 48);
     memcpy(&pn[(size_t)4 * j], n4 + (size_t)4 * i, 16);
     memcpy(&pc[(size_t)4 * j], c4 + (size_t)4 * i, 16);
-    float* b = &box[(size_t)8 * (j / 64)];
+    float* b = &box[(size_t)12 * (j / 64)];
     for (int v = 0; v < 3; ++v)
       for (int k = 0; k < 3; ++k) { b[k] = fminf(b[k], v4[(size_t)12 * i + 4 * v + k]); b[4 + k] = fmaxf(b[4 + k], v4[(size_t)12 * i + 4 * v + k]); }
+  }
+  // Per tile, for the bounce rays' tile pre-test (rt_kernel_mesh.hip tile_clear_for_bundle), in double from the float vertices:
+  //   lo.w  eta   = max over the tile's triangles of max(|e1|, |e2|, |e2 - e1|) / |e1 x e2|   (inverse altitudes)
+  //   hi.w  emax  = max edge length
+  //   third float4: unit axis of the triangles' normals (signs aligned) | chi = max |n_T - axis|_2 (chord of the normal cone)
+  // A tile with a degenerate triangle gets chi = 4: never certified clear, always visited.
+  for (int t = 0; t < ntiles; ++t) {
+    const int j0 = t * 64, j1 = (j0 + 64 < n) ? j0 + 64 : n;
+    double ax[3] = {0, 0, 0}, eta = 0.0, emax = 0.0;
+    bool degenerate = false;
+    std::vector<double> nn((size_t)(j1 - j0) * 3);
+    for (int j = j0; j < j1; ++j) {
+      const float* a = &pv[(size_t)12 * j];
+      const double e1[3] = {(double)a[4] - a[0], (double)a[5] - a[1], (double)a[6] - a[2]};
+      const double e2[3] = {(double)a[8] - a[0], (double)a[9] - a[1], (double)a[10] - a[2]};
+      double cr[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+      const double l1 = sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]), l2 = sqrt(e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]);
+      const double lc = sqrt(cr[0] * cr[0] + cr[1] * cr[1] + cr[2] * cr[2]);
+      if (!(lc > 1e-30) || !(l1 > 0) || !(l2 > 0) || !(lc >= 1e-9 * l1 * l2)) { degenerate = true; break; }
+      const double l3 = sqrt((e2[0] - e1[0]) * (e2[0] - e1[0]) + (e2[1] - e1[1]) * (e2[1] - e1[1]) + (e2[2] - e1[2]) * (e2[2] - e1[2]));
+      const double le = fmax(fmax(l1, l2), l3);
+      eta = fmax(eta, le / lc);
+      emax = fmax(emax, le);
+      double* q = &nn[(size_t)(j - j0) * 3];
+      for (int k = 0; k < 3; ++k) q[k] = cr[k] / lc;
+      if (j > j0 && q[0] * nn[0] + q[1] * nn[1] + q[2] * nn[2] < 0) for (int k = 0; k < 3; ++k) q[k] = -q[k];   // align with the first
+      for (int k = 0; k < 3; ++k) ax[k] += q[k];
+    }
+    float* b = &box[(size_t)12 * t];
+    const double la = sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+    double chi = 4.0;
+    if (!degenerate && la > 1e-12) {
+      for (int k = 0; k < 3; ++k) ax[k] /= la;
+      chi = 0.0;
+      for (int j = j0; j < j1; ++j) {
+        const double* q = &nn[(size_t)(j - j0) * 3];
+        const double dx = q[0] - ax[0], dy = q[1] - ax[1], dz = q[2] - ax[2];
+        chi = fmax(chi, sqrt(dx * dx + dy * dy + dz * dz));
+      }
+    } else {
+      ax[0] = 1.0; ax[1] = ax[2] = 0.0; eta = 1e30; emax = 1e30;
+    }
+    b[3] = (float)(eta * 1.0001); b[7] = (float)(emax * 1.0001);
+    b[8] = (float)ax[0]; b[9] = (float)ax[1]; b[10] = (float)ax[2]; b[11] = (float)(chi * 1.0001 + 1e-6);
   }
   const size_t nb = (size_t)n * sizeof(float4);
   if (hipMalloc(&c->d_verts_m, 3 * nb) != hipSuccess || hipMalloc(&c->d_normals_m, nb) != hipSuccess ||
       hipMalloc(&c->d_colors_m, nb) != hipSuccess || hipMalloc(&c->d_orig, (size_t)n * sizeof(int)) != hipSuccess ||
-      hipMalloc(&c->d_tile_box, (size_t)ntiles * 2 * sizeof(float4)) != hipSuccess) {
+      hipMalloc(&c->d_tile_box, (size_t)ntiles * 3 * sizeof(float4)) != hipSuccess) {
     set_error("hipMalloc failed: %s", hipGetErrorString(hipGetLastError())); return RT_E_NOMEM;
   }
   if (hipMemcpy(c->d_verts_m, pv.data(), 3 * nb, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(c->d_normals_m, pn.data(), nb, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(c->d_colors_m, pc.data(), nb, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(c->d_orig, orig.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(c->d_tile_box, box.data(), (size_t)ntiles * 2 * sizeof(float4), hipMemcpyHostToDevice) != hipSuccess) {
+      hipMemcpy(c->d_tile_box, box.data(), (size_t)ntiles * 3 * sizeof(float4), hipMemcpyHostToDevice) != hipSuccess) {
     set_error("scene upload failed: %s", hipGetErrorString(hipGetLastError())); return RT_E_DEVICE;
   }
   return RT_OK;

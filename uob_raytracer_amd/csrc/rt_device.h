@@ -97,13 +97,14 @@ struct FrameParams {
   unsigned int* mesh_queue_len;     // its length (a very expensive block is entered as four cooperative sub-block jobs)
   int32_t mesh_blocks;              // workgroups the device holds at once
   const int* orig;        // mesh kernel: original index of every (reordered) triangle; nullptr = the order is the original
-  const float4* tile_box; // mesh kernel: per 64-triangle tile, its vertices' box: lo.xyz, hi.xyz
+  const float4* tile_box; // mesh kernel: per 64-triangle tile, 3 float4: box lo.xyz | eta, box hi.xyz | sigma, normal-cone axis | chi (rt_api.hip)
   // mesh kernel: per-frame candidate-tile masks (rt_kernel_mesh.hip), nullptr = visit every tile
   unsigned long long* screen_masks;   // [scy][scx][nwords]: tiles a primary ray through that 64x64-pixel cell may hit
   unsigned long long* world_masks;    // [G][G][G][nwords]: tiles that may shadow a surface point inside that world cell
   unsigned int* world_occ;            // bitmaps of the world cells that can hold a surface point: G^3, (G/2)^3, (G/4)^3 bits
   int32_t mask_debug;                 // diagnostic (UOB_RT_MASK_DEBUG): 1 = ignore screen masks, 2 = ignore world masks, 4 = every world cell occupied,
-                                      // 8 = every block of the next frame cooperative (tests), 16 = a context's first frame in row order (no cost guess)
+                                      // 8 = every block of the next frame cooperative (tests), 16 = a context's first frame in row order (no cost guess),
+                                      // 64 = bounce rays visit every tile (no tile pre-test)
   int32_t nwords, scx, scy, grid_g;   // 64-bit words per mask; screen cells per row / column; world cells per axis
   float grid_lo[3], grid_cell, grid_inv;   // world grid: origin, cell edge, 1 / cell edge
 };

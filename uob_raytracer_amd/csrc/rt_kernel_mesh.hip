@@ -112,6 +112,56 @@ __device__ __forceinline__ Mask2 tile_test_pair(const float4* tv0, const float4*
   return r;
 }
 
+// ---- bounce rays: may ANY ray of a bundle hit ANY triangle of a tile? -----------------------------------------------------
+// The per-triangle bound (task_bound, lane = triangle) needs the tile in LDS; this one needs 48 bytes per tile and is asked
+// lane = tile, 64 tiles per pass, before anything is loaded.  A plain ray-box test would NOT do: for a ray that lies in a
+// triangle's plane all the determinants of the reference's test vanish, its t, u, v are rounding noise, and the reference may
+// "hit" a triangle the ray passes at any distance — noise this library must reproduce.  The certificate:
+//   With W1 = det(A1), W2 = det(A2), W0 = det(A) - W1 - W2 (the three edge functions; u = W1 / det(A), v = W2 / det(A),
+//   1 - u - v = W0 / det(A)) and any n perpendicular to the ray's direction,   sum_i W_i n.(v_i - o) = 0   holds identically
+//   (sum_i W_i (v_i - o) = det(A0) d).  Take n = d x e_k (k = x, y, z: the separating axes of a line and a box): if the
+//   tile's box lies on one side of that plane through the ray, every a_i = n.(v_i - o) is in [gap, gap + 2 rad], gap > 0.
+//   The reference accepts only if u >= 0, v >= 0, fl(u + v) <= 1, i.e. if the COMPUTED W_i all have det(A)'s sign (up to
+//   4 eps of their magnitudes); by the identity that is possible only if all three computed W_i are within
+//   Omega = 3 E (1 + 2 rad / gap) of zero, E <= 21 eps |d| (|b| + |e|) |e| bounding their rounding errors (eps = 2^-24).
+//   And they are NOT all that small unless the ray lies in the triangle's plane:   max_i |W_i| >= 0.28 theta |c| |d|   where
+//   theta <= max(|n_T . d| / |d|, |n_T . (o - v)| / bmax) (n_T the triangle's unit normal, bmax >= |o - v|): from
+//   det(A) = sum W_i and, for in-plane g, sum W_i g.(v_i - o) = det(A0) g.d.  Per tile the normals lie in a cone (unit axis a,
+//   chord chi = max |n_T -+ a|), so theta >= max(|a . d| / |d|, |a . (o - v)| / bmax) - chi, bounded over the bundle and the box.
+//   Certified clear iff  gap > 0  and  theta >= 150 eps (4 + 6 rad / gap) (bmax + emax) eta   (factor of safety 2 included),
+//   eta = max |e| / |e1 x e2| and emax = max |e| over the tile's triangles (rt_api.hip upload_tiled_scene).
+// Bundle: origins s0 +- es, directions D0 +- ed per component, |d|_2 <= dmax2.  Conservative in every term; `false` = visit.
+__device__ __forceinline__ bool tile_clear_for_bundle(const float4* __restrict__ tb, f3 s0, f3 D0, float es, float ed, float dmax2) {
+  const float4 lo4 = tb[0], hi4 = tb[1], ax4 = tb[2];
+  const float eta = lo4.w, emax = hi4.w, chi = ax4.w;
+  const f3 axis = xyz(ax4);
+  const f3 cB = 0.5f * (xyz(lo4) + xyz(hi4));
+  // (half extents with the rounding of the staged e1 = v1 - v0, e2 = v2 - v0 and of cB itself)
+  const float cs = 4e-7f * (norm_inf(xyz(lo4)) + norm_inf(xyz(hi4)));
+  const f3 hB = mk(0.5f * (hi4.x - lo4.x) * 1.00001f + cs, 0.5f * (hi4.y - lo4.y) * 1.00001f + cs, 0.5f * (hi4.z - lo4.z) * 1.00001f + cs);
+  const f3 r0 = cB - s0;
+  const float esb = es * 1.0001f + 1e-6f * norm_inf(s0);
+  const float bmax = 1.7321f * (norm_inf(r0) + fmaxf(fmaxf(hB.x, hB.y), hB.z) + esb);
+  const float rr[3] = {r0.x, r0.y, r0.z}, dd[3] = {D0.x, D0.y, D0.z}, hh[3] = {hB.x, hB.y, hB.z};
+  float ratio = 3.0e38f;                                               // smallest rad / gap over the axes that separate
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int j = (k + 1) % 3, l = (k + 2) % 3;
+    const float t1 = dd[l] * rr[j], t2 = dd[j] * rr[l];
+    const float f0 = t1 - t2;                                          // (d x e_k) . r up to sign
+    const float dev = ed * (fabsf(rr[j]) + fabsf(rr[l])) + esb * (fabsf(dd[l]) + fabsf(dd[j])) + 2.0f * ed * esb;
+    const float rad = hh[j] * (fabsf(dd[l]) + ed) + hh[l] * (fabsf(dd[j]) + ed);
+    const float gap = fabsf(f0) - dev - rad - 1e-5f * (fabsf(t1) + fabsf(t2) + dev + rad);   // (minus this evaluation's own rounding)
+    if (gap > 0.0f) ratio = fminf(ratio, rad / gap);
+  }
+  if (!(ratio < 1.0e30f)) return false;
+  const float a1 = norm1(axis);
+  const float k_line = (fabsf(bdot3(axis, D0)) - ed * a1) / dmax2;
+  const float k_orig = (fabsf(bdot3(axis, r0)) - (fabsf(axis.x) * hB.x + fabsf(axis.y) * hB.y + fabsf(axis.z) * hB.z) - esb * a1) / bmax;
+  const float theta = fmaxf(k_line, k_orig) * 0.9999f - chi;
+  return theta >= 8.95e-6f * (4.0f + 6.0f * ratio) * (bmax + emax) * eta;     // 150 * 2^-24 = 8.94e-6
+}
+
 // Geometry of a wave's 8x8 pixel block: its 64 pixels are numbered along a Z-order curve (x bits 0,2,4 / y bits
 // 1,3,5 of the number), task k covers the PT consecutive numbers from k*PT — for a power of two PT a compact
 // rectangle (4x2, 4x4, 8x4 ...), PTx >= PTy; for any other PT (AA grids such as 3x3: PT = 7) a compact run of the curve.
@@ -659,10 +709,49 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
               }
             }
         };
-        for (int t0 = 0; t0 < ntiles; t0 += kBatch) {
-          const int cnt = (ntiles - t0) < kBatch ? (ntiles - t0) : kBatch;
-          load_batch(t0, t0 + 1, t0 + 2, t0 + 3, cnt, false);
-          for (int sl = 0; sl < cnt; ++sl) bounce_tile(t0 + sl, tile + sl * kSlot);
+        // Which tiles?  lane = tile, 64 tiles per pass (tile_clear_for_bundle), the four waves' answers OR-ed into the
+        // workgroup's tile mask; RT_FLAG_NO_TILE_BINS (no masks at all) streams every tile as before.
+        __syncthreads();
+        for (int w = tid; w < nwords; w += 64 * kMeshWaves) smask[w] = 0ull;
+        __syncthreads();
+        if (actm != 0ull && mode != 0) {
+          const bool pretest = bins && mode == 1 && PC(tile_box) != nullptr && !(PC(mask_debug) & 64);
+          // |d|_2 of the wave's rays (they are normalised: 1 within rounding; lanes without a ray contribute 0)
+          const float d2 = pretest ? 1.0001f * bsqrt(wave_max_pos((act && mode == 1) ? dot3(ray.dir, ray.dir) : 0.0f)) * 1.0001f : 0.0f;
+          for (int base = 0; base < ntiles; base += 64) {
+            const int t = base + lane;
+            bool visit = t < ntiles;
+            if (pretest && visit) visit = !tile_clear_for_bundle(PC(tile_box) + (size_t)3 * t, s0, D0, es, ed, d2);
+            const unsigned long long vm = ballot(visit);
+            if (lane == 0 && vm != 0ull) atomicOr(&smask[base >> 6], vm);
+          }
+        }
+        __syncthreads();
+        {
+          int bw = -1;
+          unsigned long long bm = 0ull;
+          for (;;) {
+            int t0 = -1, t1 = -1, t2 = -1, t3 = -1, cnt = 0;
+            if ((t0 = next_tile(smask, bw, bm)) >= 0) { cnt = 1;
+              if ((t1 = next_tile(smask, bw, bm)) >= 0) { cnt = 2;
+                if ((t2 = next_tile(smask, bw, bm)) >= 0) { cnt = 3;
+                  if ((t3 = next_tile(smask, bw, bm)) >= 0) cnt = 4; } } }
+            if (cnt == 0) break;
+            load_batch(t0, t1, t2, t3, cnt, false);
+            if (COUNT && actm != 0ull) xw[0] += cnt;                     // (diagnostic: bounce-round tile visits count as primary visits)
+            for (int sl = 0; sl < cnt; ++sl)
+              if (!coop || sl == wave) bounce_tile(sl == 0 ? t0 : sl == 1 ? t1 : sl == 2 ? t2 : t3, tile + sl * kSlot);
+            if (cnt < kBatch) break;
+          }
+        }
+        if (coop) {      // cooperative block: the four waves hold the SAME rays and took a tile each — closest hit = smallest (t, original index)
+          coop_hit[wave * 64 + lane] = CoopHit{cur, hu, hv, hit, hit_o};
+          __syncthreads();
+          for (int w = 0; w < kMeshWaves; ++w) {
+            const CoopHit h = coop_hit[w * 64 + lane];
+            if (h.best >= 0 && (hit < 0 || h.t < cur || (h.t == cur && h.orig < hit_o))) { cur = h.t; hu = h.u; hv = h.v; hit = h.best; hit_o = h.orig; }
+          }
+          __syncthreads();
         }
         if (act) {
           if (hit >= 0) {
@@ -1068,6 +1157,24 @@ __global__ void rt_mesh_estimate(const FrameParams P, unsigned int* cost, int n_
   const int cx = (job_x * 16) >> kScreenCellLog, cy = band_global_row(P, lrr) >> kScreenCellLog;
   unsigned int c = 1u;
   for (int w = 0; w < P.nwords; ++w) c += (unsigned int)__popcll(P.screen_masks[((size_t)cy * P.scx + cx) * P.nwords + w]);
+  // A block that looks at a mirror or glass sphere sends bounce rays through every tile for up to `bounces` rounds: by far
+  // the dearest blocks of a frame (configs[4] + the reference's spheres: a block on a sphere's rim 15 ms, the frame without
+  // them 8 ms).  Counted as all tiles, twice: rt_mesh_order then enters them as cooperative jobs, whose four waves share each
+  // round's tiles — in the first frame already (30 -> ms, profiles/r03_mesh.txt).
+  if (P.bounces > 0) {
+    const float xc = (float)(job_x * 16 + 8), yc = (float)(band_global_row(P, lrr + 8 < P.owned_rows ? lrr + 8 : P.owned_rows - 1));
+    for (int i = 0; i < P.nsph; ++i) {
+      if (P.sph[i].col[3] > 0.0f || !(P.sph[i].r2 > 0.0f)) continue;
+      const f3 v = mk(P.sph[i].cx - P.cam[0], P.sph[i].cy - P.cam[1], P.sph[i].cz - P.cam[2]);
+      // d = R^T v (the primary ray through pixel (x, y) is R (x aa_x - half_wx, (y aa_y - half_hy) sy, focal), rt_trace.h)
+      const f3 q = mk(P.rot[0] * v.x + P.rot[4] * v.y + P.rot[8] * v.z, P.rot[1] * v.x + P.rot[5] * v.y + P.rot[9] * v.z,
+                      P.rot[2] * v.x + P.rot[6] * v.y + P.rot[10] * v.z);
+      if (!(q.z > 1e-6f)) continue;
+      const float sx = (q.x / q.z * P.focal + P.half_wx) / (float)P.aa_x, sy_ = (q.y / q.z * P.focal / P.sy + P.half_hy) / (float)P.aa_y;
+      const float rp = sqrtf(P.sph[i].r2) / q.z * P.focal / (float)P.aa_x * 1.1f + 12.0f;     // projected radius, generous
+      if ((xc - sx) * (xc - sx) + (yc - sy_) * (yc - sy_) <= rp * rp) c += 2u * (unsigned int)(64 * P.nwords);
+    }
+  }
   cost[job] = c;
 }
 
