@@ -1,12 +1,12 @@
 """Throughput of ONE rank's bands of an N-rank job when consecutive frames come from M contexts on M streams (the tail of
 frame k overlaps the start of frame k+1) against one context on one stream — the render alone, no gather.
-usage: band_pipeline.py [N ...]      env: BANDS (band rows, default 8), RANK (default 0), CONTEXTS (default "1 2")"""
+usage: band_pipeline.py [N ...]      env: BANDS (band rows, default 16), RANK (default 0), CONTEXTS (default "1 2")"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from uob_raytracer_amd import abi, runtime as rt
 rot, cam, light = rt.rotation_matrix(0, 0), [0, 0, -3.2], [0, -0.5, -0.7]
-br, rank = int(os.environ.get("BANDS", "8")), int(os.environ.get("RANK", "0"))
+br, rank = int(os.environ.get("BANDS", "16")), int(os.environ.get("RANK", "0"))
 for bc in [int(v) for v in (sys.argv[1:] or ["8"])]:
     cfg = abi.make_config(width=4096, height=4096, aa_x=4, aa_y=2, shadow_samples=64, band_rows=br if bc > 1 else 0, band_index=rank % bc, band_count=bc)
     for M in [int(v) for v in os.environ.get("CONTEXTS", "1 2").split()]:

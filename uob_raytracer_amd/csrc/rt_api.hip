@@ -232,6 +232,45 @@ static int upload_tiled_scene(rt_ctx* c, const float* v4, const float* n4, const
     key[(size_t)i] = std::make_pair(code, i);
   }
   std::stable_sort(key.begin(), key.end(), [](const std::pair<uint32_t, int>& x, const std::pair<uint32_t, int>& y) { return x.first < y.first; });
+  // UOB_RT_TILE_ORDER=kd (default): the small triangles are not left in Morton order (runs of 64 along a space-filling curve
+  // jump between octants: a quarter of this round's test mesh's tiles had a normal-cone chord above 0.8) but split top-down at
+  // the median of the longest axis of their centroids' box, every cut on a tile boundary, until a range is one tile: compact
+  // boxes, compact normal cones.  =morton keeps round 2's order (A/B).  The order is a free choice (see above).
+  {
+    const char* mode = getenv("UOB_RT_TILE_ORDER");
+    int nb = 0;
+    while (nb < n && key[(size_t)nb].first == 0u) ++nb;                  // the large triangles, in original order
+    if (!(mode && !strcmp(mode, "morton")) && n - nb > 64) {
+      std::vector<float> cen((size_t)n * 3);
+      for (int i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k) cen[(size_t)3 * i + k] = (v4[(size_t)12 * i + k] + v4[(size_t)12 * i + 4 + k] + v4[(size_t)12 * i + 8 + k]) * (1.0f / 3.0f);
+      std::vector<int> idx((size_t)(n - nb));
+      for (int j = nb; j < n; ++j) idx[(size_t)(j - nb)] = key[(size_t)j].second;
+      // ranges [b, e) of idx; position p of idx is position nb + p of the tiled order: cuts where (nb + p) % 64 == 0
+      std::vector<std::pair<int, int>> stack;
+      stack.push_back(std::make_pair(0, n - nb));
+      while (!stack.empty()) {
+        const int b = stack.back().first, e = stack.back().second;
+        stack.pop_back();
+        if ((nb + b) / 64 == (nb + e - 1) / 64) continue;               // one tile
+        float clo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, chi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+        for (int p = b; p < e; ++p)
+          for (int k = 0; k < 3; ++k) { clo[k] = fminf(clo[k], cen[(size_t)3 * idx[(size_t)p] + k]); chi[k] = fmaxf(chi[k], cen[(size_t)3 * idx[(size_t)p] + k]); }
+        int ax = 0;
+        if (chi[1] - clo[1] > chi[ax] - clo[ax]) ax = 1;
+        if (chi[2] - clo[2] > chi[ax] - clo[ax]) ax = 2;
+        // the tile boundary nearest to the middle of the range
+        const int first_cut = ((nb + b) / 64 + 1) * 64 - nb, last_cut = ((nb + e - 1) / 64) * 64 - nb;
+        int m = ((nb + (b + e) / 2 + 32) / 64) * 64 - nb;
+        m = m < first_cut ? first_cut : (m > last_cut ? last_cut : m);
+        std::nth_element(idx.begin() + b, idx.begin() + m, idx.begin() + e,
+                         [&](int x, int y) { return cen[(size_t)3 * x + ax] < cen[(size_t)3 * y + ax] || (cen[(size_t)3 * x + ax] == cen[(size_t)3 * y + ax] && x < y); });
+        stack.push_back(std::make_pair(b, m));
+        stack.push_back(std::make_pair(m, e));
+      }
+      for (int j = nb; j < n; ++j) key[(size_t)j].second = idx[(size_t)(j - nb)];
+    }
+  }
   const int ntiles = mesh_tiles(n);
   std::vector<float> pv((size_t)n * 12), pn((size_t)n * 4), pc((size_t)n * 4), box((size_t)ntiles * 12);
   std::vector<int> orig((size_t)n);
