@@ -51,7 +51,7 @@ typedef struct rt_sphere {
  * rt_config_default() fills in the reference's shipped values.                                   */
 typedef struct rt_config {
   int32_t width, height;        /* SCREEN_WIDTH / SCREEN_HEIGHT, kernels.cl:16-17, skeleton.cpp:32-33 */
-  int32_t aa_x, aa_y;           /* rays_x / rays_y, kernels.cl:12-13 (aa_rays = aa_x*aa_y)            */
+  int32_t aa_x, aa_y;           /* rays_x / rays_y, kernels.cl:12-13 (aa_rays = aa_x*aa_y); each 1..16        */
   int32_t shadow_samples;       /* light_sources, kernels.cl:316                                       */
   float   light_spread;         /* kernels.cl:317                                                      */
   int32_t max_bounces;          /* bounces, kernels.cl:343                                             */

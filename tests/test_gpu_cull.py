@@ -154,3 +154,30 @@ def test_specialised_instantiations_equal_the_generic_one(aa, S, scene, oracle):
         cfg = abi.make_config(**kw)
         want, _ = oracle.render(cfg, v, n, c, rot, cam, LIGHTS[1], focal_for(cfg), pix=pix, nthreads=8)
         assert np.array_equal(a0.ravel()[pix], want)
+
+
+@pytest.mark.parametrize("aa", [(9, 9), (16, 8), (11, 7), (16, 16), (13, 5)])
+def test_more_than_64_aa_samples_on_the_wave_kernel(aa, scene, oracle):
+    """AA grids of 65..256 samples per pixel (the reference's grid is a pair of constants, kernels.cl:12-14) run on the wave
+    kernel in chunks of 64 samples, the pixel's running sum carried from chunk to chunk in sample order: identical to the
+    generic (thread-per-pixel) kernel and to the CPU oracle, ARGB and float tap, two views, ragged width."""
+    kw = dict(width=83, height=40, aa_x=aa[0], aa_y=aa[1], shadow_samples=[64, 10, 33][aa[0] % 3])
+    cfg = abi.make_config(**kw)
+    v, n, c = scene.packed()
+    for yaw, pitch, cam in CAMS[:2]:
+        rot = rt.rotation_matrix(yaw, pitch)
+        a0, f0 = _render(kw, 0, scene, rot, cam, LIGHTS[1])
+        a2, f2 = _render(kw, abi.RT_FLAG_GENERIC_KERNEL, scene, rot, cam, LIGHTS[1])
+        assert np.array_equal(a0, a2) and np.array_equal(f0.view(np.uint32), f2.view(np.uint32))
+        want, want_rgb = oracle.render(cfg, v, n, c, rot, cam, LIGHTS[1], focal_for(cfg), nthreads=8)
+        assert np.array_equal(a0.ravel(), want)
+        assert np.array_equal(f0.reshape(-1, 4)[:, :3].view(np.uint32), want_rgb.view(np.uint32))
+    # consecutive frames of one context (expensive-job list in use) and a band partition
+    kwb = dict(kw, band_rows=8, band_index=1, band_count=2)
+    tr = rt.RayTracer(abi.make_config(**kwb), scene)
+    rows = [y for y in range(40) if (y // 8) % 2 == 1]
+    for _ in range(3):
+        got = tr.render(rt.rotation_matrix(*CAMS[0][:2]), CAMS[0][2], LIGHTS[1], focal_for(cfg))
+    tr.close()
+    ref, _ = _render(kw, abi.RT_FLAG_GENERIC_KERNEL, scene, rt.rotation_matrix(*CAMS[0][:2]), CAMS[0][2], LIGHTS[1])
+    assert np.array_equal(got, ref[rows])

@@ -505,7 +505,7 @@ int rt_init(const rt_config* cfg, const float* vertices4, const float* normals4,
   }
   {   // wave kernel: lists of last frame's expensive jobs (sized for the smallest job, one 64-ray task)
     const int aa = cfg->aa_x * cfg->aa_y;
-    const int pt = (aa >= 1 && aa <= 64) ? 64 / aa : 64;
+    const int pt = (aa >= 1 && aa <= 64) ? 64 / aa : 16;        // smallest job: one task; more than 64 AA samples: 16 pixels
     const size_t jobs_max = (size_t)((cfg->width + pt - 1) / pt) * (size_t)(c->owned_rows > 0 ? c->owned_rows : 1);
     c->heavy_cap = (int)(jobs_max / 3 > 64 ? jobs_max / 3 : 64);
     c->heavy_jobs_max = jobs_max;
@@ -603,6 +603,7 @@ static void fill_params(const rt_ctx* c, const float rot[12], const float cam[3]
   {   // wave kernel: a job is a run of job_tasks 64-ray tasks (job_tasks * 64/aa pixels) of one row
     const int aa = g.aa_x * g.aa_y;
     const bool wave_aa = aa >= 1 && aa <= 64;
+    const int big_chunks = aa > 64 ? (aa + 63) / 64 : 0;      // 65..256 AA samples: a pixel is big_chunks tasks (rt_kernel_wave.hip BIGAA)
     // Job size: up to 64 pixels, halved while the queue would hold fewer than ~16 jobs per resident wave (jobs differ
     // 10x in cost, but every hand-out stalls its wave for microseconds; measured with last frame's expensive jobs
     // going first: 4096 and 2048 rows -> 64 px, 1024 and 512 rows -> 32 px), but not below 16 pixels.
@@ -619,12 +620,19 @@ static void fill_params(const rt_ctx* c, const float rot[12], const float cam[3]
     // (the knob may not make a job smaller than 16 pixels: div_magic's exactness bound, rt_device.h, is stated for >= 16)
     if (wave_aa && c->tune.job_tasks >= 1 && c->tune.job_tasks * pt <= 64 && (c->tune.job_tasks * pt >= 16 || c->tune.job_tasks >= jt))
       jt = c->tune.job_tasks;
+    if (big_chunks) jt = 16 * big_chunks;                      // jobs of 16 pixels
     // job / nseg by one multiply-high (rt_device.h div_magic) is exact while (njobs - 1) * (magic * nseg - 2^32) < 2^32.
     // Every accepted frame with jobs of 16+ pixels satisfies it; a knob that asks for smaller jobs is honoured only as far
     // as the bound still holds (checked here, not assumed): the job is doubled until it does.
     int job_pixels = 0;
     for (;;) {
-      job_pixels = jt * pt;
+      job_pixels = big_chunks ? jt / big_chunks : jt * pt;
+      if (big_chunks) {
+        P->nseg = (g.width + job_pixels - 1) / job_pixels;
+        P->njobs = P->nseg * c->owned_rows;
+        P->nseg_magic = P->nseg > 1 ? (uint32_t)((0x100000000ull + (uint64_t)P->nseg - 1) / (uint64_t)P->nseg) : 0u;
+        break;                                                   // 16-pixel jobs: within div_magic's bound for every accepted frame
+      }
       P->nseg = (g.width + job_pixels - 1) / job_pixels;
       P->njobs = P->nseg * c->owned_rows;
       P->nseg_magic = P->nseg > 1 ? (uint32_t)((0x100000000ull + (uint64_t)P->nseg - 1) / (uint64_t)P->nseg) : 0u;
@@ -635,7 +643,7 @@ static void fill_params(const rt_ctx* c, const float rot[12], const float cam[3]
     P->job_tasks = jt;
     // (measured on one rank's 512 rows of the headline frame, whose longest jobs last 0.5 of its 0.57 ms: 0.570 ms with,
     // 0.566 without — the span is set by the work per wave and the ~60 us tail, not by the longest job; off unless asked for)
-    P->split_listed = c->tune.split_listed == 1 && jt > 1 ? 1 : 0;
+    P->split_listed = c->tune.split_listed == 1 && jt > 1 && !big_chunks ? 1 : 0;
     P->no_specialise = c->tune.no_specialise ? 1 : 0;
     P->job_hx = 0.5f * (float)(job_pixels * g.aa_x - 1);
     P->job_hy = 0.5f * (float)(g.aa_y - 1) * P->sy;
@@ -698,7 +706,7 @@ static int launch_frame(rt_ctx* c, const float rot[12], const float cam[3], cons
   if (c->timed && stream != c->last_stream) HIP_TRY(hipStreamWaitEvent(stream, c->ev1, 0));
   HIP_TRY(hipEventRecord(c->ev0, stream));
   const bool wave_paths = !(c->cfg.flags & RT_FLAG_GENERIC_KERNEL);
-  if (wave_paths && wave_kernel_supports(P)) {
+  if (wave_paths && wave_kernel_supports(P) && (P.aa_x * P.aa_y <= 64 || !(c->cfg.flags & RT_FLAG_NO_CULL))) {
     // last frame's expensive jobs first — where jobs are long enough (4+ tasks) for the extra look-up per
     // hand-out not to matter (measured: 1024^2 frames with 16-pixel jobs lose 12-18 % to it, larger ones gain 2-8 %)
     if (c->d_heavy_flags && P.job_tasks >= 4) {
@@ -1017,7 +1025,7 @@ int rt_count_executed(rt_ctx* c, const float rot[12], const float cam[3], const 
   fill_params(c, rot, cam, light, focal, &P);
   const bool generic = (c->cfg.flags & RT_FLAG_GENERIC_KERNEL) != 0;
   const bool mesh = !generic && !wave_kernel_supports(P) && !(c->cfg.flags & RT_FLAG_NO_CULL) && mesh_kernel_supports(P);
-  if (generic || (!wave_kernel_supports(P) && !mesh) || (!mesh && P.S > 64)) {
+  if (generic || (!wave_kernel_supports(P) && !mesh) || (!mesh && (P.S > 64 || P.aa_x * P.aa_y > 64))) {
     set_error("rt_count_executed: this configuration runs on the generic kernel, whose executed work is rt_count_work");
     return RT_E_UNSUPPORTED;
   }

@@ -261,7 +261,10 @@ __host__ __device__ constexpr int wave_fixed_lds_float4() {
 // samples)"): the lane <-> (pixel, AA sample) arithmetic becomes shifts, the 64 adds of direct_light's sum and the AA sum
 // straight-line code, and a dozen wave-uniform conditions (and the scalar registers they were spilled from) disappear.
 // Same operations on the same values: the frame is bit-identical to the generic instantiation's (tests/test_gpu_cull.py).
-template <bool CULL, bool COUNT, bool PROF = false, int STRIDE = 0, bool MULTI = false, int AA_X = 0, int AA_Y = 0, int SS = 0>
+// BIGAA: 65..256 AA samples per pixel (the reference's grid is a pair of constants, kernels.cl:12-14): a pixel's samples are
+// worked off in chunks of 64 — a task is one chunk of ONE pixel, a job's tasks run pixel by pixel, chunk by chunk, and the
+// pixel's running sum (final_color_total +=, :415-425, in sample order) is carried from chunk to chunk.
+template <bool CULL, bool COUNT, bool PROF = false, int STRIDE = 0, bool MULTI = false, int AA_X = 0, int AA_Y = 0, int SS = 0, bool BIGAA = false>
 // 5 waves per SIMD (<= 96 VGPRs; what spills is written once per wave, outside the loops): the kernel is bound by
 // instruction issue and needs the waves — 5 per SIMD measured 3.76 ms against 4.10 ms at 4 (128 VGPRs)
 #ifndef RT_MIN_WAVES
@@ -307,8 +310,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
   const LdsScene S = lds_scene(lds, n, st);
   const int aa_x = AA_X ? AA_X : P.aa_x, aa_y = AA_Y ? AA_Y : P.aa_y;
   const float sy = (AA_X && AA_Y) ? (float)AA_X / (float)AA_Y : P.sy;
-  const int aa = aa_x * aa_y;                                         // 1..64 AA samples per pixel (supports())
-  const int PT = 64 / aa;                                             // pixels per task (lanes >= PT * aa idle)
+  const int aa_full = aa_x * aa_y;                                    // AA samples per pixel: 1..64, BIGAA: 65..256 (supports())
+  const int chunks = BIGAA ? (aa_full + 63) >> 6 : 1;                 // tasks per pixel
+  const int aa = BIGAA ? 64 : aa_full;                                // lanes of one pixel in a task (BIGAA: one chunk of its samples)
+  const int PT = BIGAA ? 1 : 64 / aa;                                 // pixels per task (lanes >= PT * aa idle)
+  f3 aa_run = mk(0.f, 0.f, 0.f);                                      // BIGAA: the current pixel's running AA sum
   const int GP = PT < kRngPixels ? PT : kRngPixels;                   // pixels per RNG group
   const int gp_magic = (65536 + GP - 1) / GP;                         // q / GP == (q * gp_magic) >> 16 for q < 64
   const f3 light = mk(P.light[0], P.light[1], P.light[2]);
@@ -428,7 +434,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
   const int jrow = (int)div_magic((uint32_t)job, PC(nseg_magic));
   const int mid = (PC(owned_rows) + 1) >> 1;
   const int lr = (jrow & 1) ? mid + (jrow >> 1) : mid - 1 - (jrow >> 1);
-  const int JP = jt * PT;                          // pixels of this hand-out
+  const int JP = BIGAA ? jt / chunks : jt * PT;    // pixels of this hand-out
   const int x0 = (job - jrow * PC(nseg)) * JP;
   const int y = band_global_row_cold(P, lr);
   f3 outc = mk(0.f, 0.f, 0.f);
@@ -460,11 +466,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
   for (int k = k0; k < k1; ++k) {
     const int lnA = opaque(lane);
     // ---- phase 1: 64 primary rays, lnA = (pixel, AA sample) -----------------------------------------
-    const int pA = (AA_X && AA_Y) ? lnA / (AA_X * AA_Y ? AA_X * AA_Y : 1) : (lnA * P.aa_magic) >> 16;   // lnA / aa
-    const int pj = k * PT + pA;                // pixel of this lnA within the job
-    const int a = lnA - pA * aa;               // AA sample index dy*rx+dx, kernels.cl:395
+    const int kp = BIGAA ? k / chunks : k;     // BIGAA: the pixel (within the job) this task belongs to, and which chunk of its samples
+    const int chunk = BIGAA ? k - kp * chunks : 0;
+    const int pA = BIGAA ? 0 : ((AA_X && AA_Y) ? lnA / (AA_X * AA_Y ? AA_X * AA_Y : 1) : (lnA * P.aa_magic) >> 16);   // lnA / aa
+    const int pj = kp * PT + pA;               // pixel of this lnA within the job
+    const int a = (lnA - pA * aa) + 64 * chunk;   // AA sample index dy*rx+dx, kernels.cl:395
     const int x = x0 + pj;
-    const bool valid = x < P.W && pA < PT;
+    const bool valid = x < P.W && pA < PT && (!BIGAA || a < aa_full);
     const int ay = AA_X ? a / (AA_X ? AA_X : 1) : (a * P.aax_magic) >> 16;        // a / aa_x (a < 256)
     Ray ray = primary_ray(P, x, y, a - ay * aa_x, ay, aa_x, aa_y, sy);
     bool lit = false, secondary = false;
@@ -648,7 +656,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
         uint32_t* dst = L.rng + pp * kRngStride + comp;
         uint32_t s;
         if (!MULTI || pass == 0) {
-          const int gid = pixel_global_id(P, x0 + k * PT + g * GP + pp, y);
+          const int gid = pixel_global_id(P, x0 + kp * PT + g * GP + pp, y);
           const uint32_t seed = comp == 0 ? (uint32_t)gid : (uint32_t)((float)gid * (comp == 1 ? 91.0f : 19.0f));
           s = xorshift(seed);
         } else {
@@ -730,20 +738,28 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
     }
     // sum the AA rays of each pixel in index order (final_color_total +=, :415-425); a ray without a
     // contribution adds +0, which leaves the running sum unchanged bit for bit
+    if (BIGAA) {
+      // the pixel's samples of this chunk in index order onto its running sum (a lane without a ray adds +0: a no-op)
+      if (chunk == 0) aa_run = mk(0.f, 0.f, 0.f);
+#pragma unroll 8
+      for (int r = 0; r < 64; ++r) aa_run = aa_run + mk(rl(contrib.x, r), rl(contrib.y, r), rl(contrib.z, r));
+      if (chunk == chunks - 1 && lnD == kp) outc = aa_run;
+    } else {
     const f3 acc = aa_sum(contrib, aa, ((AA_X && AA_Y) ? lnD / (AA_X * AA_Y ? AA_X * AA_Y : 1) : (lnD * P.aa_magic) >> 16) * aa);
-    // pixel pj's sum lives in lanes [pj*aa, pj*aa+aa); hand it to output lnD (k*PT + pj)
-    {
-      const int rel = lnD - k * PT;
-      const int srcl = (rel >= 0 && rel < PT) ? rel * aa : 0;
-      const f3 v = mk(shfl(acc.x, srcl), shfl(acc.y, srcl), shfl(acc.z, srcl));
-      if (rel >= 0 && rel < PT) outc = v;
+      // pixel pj's sum lives in lanes [pj*aa, pj*aa+aa); hand it to output lnD (k*PT + pj)
+      {
+        const int rel = lnD - k * PT;
+        const int srcl = (rel >= 0 && rel < PT) ? rel * aa : 0;
+        const f3 v = mk(shfl(acc.x, srcl), shfl(acc.y, srcl), shfl(acc.z, srcl));
+        if (rel >= 0 && rel < PT) outc = v;
+      }
     }
     RT_STAMP(6)                             // 6: shading + AA sum
   }
   // ---- store: the job's consecutive pixels, one coalesced access per wave ------------------------------
   const int x = x0 + lane;
-  if (!COUNT && !PROF && lane >= k0 * PT && lane < k1 * PT && x < P.W) {
-    const f3 c = mk(div_count(outc.x, aa, inv_aa), div_count(outc.y, aa, inv_aa), div_count(outc.z, aa, inv_aa));
+  if (!COUNT && !PROF && (BIGAA ? lane < JP : (lane >= k0 * PT && lane < k1 * PT)) && x < P.W) {
+    const f3 c = mk(div_count(outc.x, aa_full, inv_aa), div_count(outc.y, aa_full, inv_aa), div_count(outc.z, aa_full, inv_aa));
     const size_t o = (size_t)(PC(out_global) ? y : lr) * P.W + x;
     PC(out_argb)[o] = pack_argb(c);
     if (PC(out_rgb)) PC(out_rgb)[o] = make_float4(c.x, c.y, c.z, 1.0f);
@@ -801,10 +817,12 @@ template __global__ void rt_draw_wave<true, false, false, 32, false, 2, 2, 64>(c
 template __global__ void rt_draw_wave<true, false, false, 32, false, 2, 2, 16>(const FrameParams);   // configs[1]
 template __global__ void rt_draw_wave<true, false, false, 32, false, 2, 2, 10>(const FrameParams);   // the reference's own constants, configs[2]
 template __global__ void rt_draw_wave<false, false, false, 0, true>(const FrameParams);
+template __global__ void rt_draw_wave<true, false, false, 0, false, 0, 0, 0, true>(const FrameParams);   // 65..256 AA samples per pixel
 
 bool wave_kernel_supports(const FrameParams& P) {
   const int aa = P.aa_x * P.aa_y;
-  return P.S >= 1 && P.S <= 4096 && aa >= 1 && aa <= 64 && P.n >= 1 && P.n <= 64 && P.n_shadow >= 1 &&
+  // (more than 64 AA samples per pixel: the chunked instantiation exists for <= 64 shadow samples, with the cull)
+  return P.S >= 1 && P.S <= 4096 && aa >= 1 && (aa <= 64 || (aa <= 256 && P.S <= 64)) && P.n >= 1 && P.n <= 64 && P.n_shadow >= 1 &&
          P.spread >= 0.0f;
 }
 
@@ -838,7 +856,9 @@ void launch_wave(const FrameParams& P, bool cull, bool count, hipStream_t stream
   } else {
     hipMemsetAsync(P.job_counter, 0, heads_bytes, stream);
   }
-  if (count) {
+  if (P.aa_x * P.aa_y > 64) {               // (callers: cull on, no counting — launch_frame / rt_count_executed check)
+    hipLaunchKernelGGL((rt_draw_wave<true, false, false, 0, false, 0, 0, 0, true>), grid, block, lds_bytes, stream, P);
+  } else if (count) {
     if (cull) hipLaunchKernelGGL((rt_draw_wave<true, true>), grid, block, lds_bytes, stream, P);
     else hipLaunchKernelGGL((rt_draw_wave<false, true>), grid, block, lds_bytes, stream, P);
   } else if (P.S > 64) {
