@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 step() { echo "=== $1"; shift; timeout -k 10 "$@" ; echo "=== exit $?"; }
 step tests 500 python -m pytest tests -x -q -m gpu > $OUT/tests.log 2>&1; tail -3 $OUT/tests.log
 # counters of every workload on THIS build, then the bench lines that price them
-for w in headline cfg2 cfg3 cfg5; do
+for w in headline cfg2 cfg3 cfg5 reference; do
   extra=""; [ $w != headline ] && extra="--workload $w"
   timeout -k 10 400 bash tools/pmc_passes.sh final/pmc_$w $extra > $OUT/pmc_$w.log 2>&1
   python tools/pmc_to_json.py $OUT/pmc_$w $w profiles/r03_pmc.json > $OUT/pmc_json_$w.log 2>&1 || echo "pmc_to_json $w failed"
