@@ -78,6 +78,7 @@ struct Tuning {
   int heavy_factor4 = 8;      // UOB_RT_HEAVY_FACTOR4: a job is expensive above this / 4 times the average cost
   bool plain_order = false;   // RT_FLAG_PLAIN_ORDER or UOB_RT_PLAIN_ORDER
   bool full_grid = false;     // UOB_RT_FULL_GRID: a rank of a multi-GPU job fills every wave slot too
+  float l1_inflate = 3.5f;    // UOB_RT_L1_INFLATE: width of the point set level 1 bounds, in units of the task's own spread (1 .. 64)
   bool heavy_dilate = true;   // UOB_RT_HEAVY_DILATE=0: expensive jobs are listed without their row neighbours
   bool no_specialise = false; // UOB_RT_NO_SPECIALISE: the generic wave-kernel instantiation also where a specialised one exists
   int grid_per_cu = 0;        // UOB_RT_GRID_PER_CU: workgroups per CU of the wave kernel's persistent grid (experiments)
@@ -178,6 +179,7 @@ static Tuning read_tuning(const rt_config& cfg) {
   t.full_grid = getenv("UOB_RT_FULL_GRID") != nullptr;
   t.no_specialise = getenv("UOB_RT_NO_SPECIALISE") != nullptr;
   if (const char* e = getenv("UOB_RT_HEAVY_DILATE")) t.heavy_dilate = atoi(e) != 0;
+  if (const char* e = getenv("UOB_RT_L1_INFLATE")) { const float v = (float)atof(e); if (v >= 1.0f && v <= 64.0f) t.l1_inflate = v; }
   if (const char* e = getenv("UOB_RT_GRID_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 8) t.grid_per_cu = v; }
   t.phase_profile = getenv("UOB_RT_PHASE_PROFILE") != nullptr;
   t.timeline = getenv("UOB_RT_TIMELINE") != nullptr;
@@ -645,6 +647,7 @@ static void fill_params(const rt_ctx* c, const float rot[12], const float cam[3]
     // 0.566 without — the span is set by the work per wave and the ~60 us tail, not by the longest job; off unless asked for)
     P->split_listed = c->tune.split_listed == 1 && jt > 1 && !big_chunks ? 1 : 0;
     P->no_specialise = c->tune.no_specialise ? 1 : 0;
+    P->l1_inflate = c->tune.l1_inflate;
     P->job_hx = 0.5f * (float)(job_pixels * g.aa_x - 1);
     P->job_hy = 0.5f * (float)(g.aa_y - 1) * P->sy;
     for (int k = 0; k < 3; ++k)

@@ -88,6 +88,8 @@ struct FrameParams {
   uint32_t heavy_gen;
   int32_t heavy_factor4;              // a job is expensive above heavy_factor4 / 4 times the average job cost
   int32_t heavy_cap;
+  float l1_inflate;                   // wave kernel: level 1 bounds a point set this many times as wide as the task's own, and the job's
+                                      // next tasks reuse it while they stay inside (1 = the task's own set, nothing to reuse)
   int32_t heavy_dilate;               // 1: an expensive job is listed together with its two neighbours in the row
   float4* records;        // staged triangle records in HBM (8 x n float4), used when n exceeds one LDS stage
   // mesh kernel: persistent workgroups pull 16x16-pixel blocks; last frame's expensive blocks first

@@ -43,6 +43,9 @@
 #ifndef RT_OPT_LIGHTSIDE
 #define RT_OPT_LIGHTSIDE 1
 #endif
+#ifndef RT_OPT_JOBK
+#define RT_OPT_JOBK 1       // level 1 of a wider point set, reused by the job's next tasks
+#endif
 #ifndef RT_OPT_TASKSPH
 #define RT_OPT_TASKSPH 1
 #endif
@@ -438,6 +441,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
   const int x0 = (job - jrow * PC(nseg)) * JP;
   const int y = band_global_row_cold(P, lr);
   f3 outc = mk(0.f, 0.f, 0.f);
+  // Level 1 of a WIDER point set than the task's, reused by the job's next tasks while their points stay inside it (below)
+  bool jk_valid = false, jk_sph = false, jk_blocked = false;
+  f3 jk_D0 = mk(0.f, 0.f, 0.f);
+  float jk_ed = 0.0f;
+  unsigned long long jk_K = 0ull;
   // Triangles a primary ray of this job may hit, bounded once for the job's 64 x 1 pixels (all AA samples): the
   // rays leave the camera through a sub-pixel rectangle, see primary_clear.  (Per task the rectangle is 8x
   // narrower and a triangle or so fewer survives, but the bound itself costs more than that triangle's tests.)
@@ -564,19 +572,38 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
       sb.maybe = false; sb.all_blocked = false;
       bool task_sph = P.nsph > 0;                  // may any shadow ray of the task touch a shadow-casting sphere?
       {
-        const int jr = __builtin_ctzll(work);
+        const bool all_sane = ballot(lit && !sane) == 0ull;
+        // A bound is a statement about a SET of shadow rays and holds for every subset.  The set bounded here is wider than the
+        // task's own — every direction within PC(l1_inflate) x the task's spread of a reference direction — and the job's next
+        // tasks (neighbouring pixels of the same row, mostly on the same surface) reuse its outcome while their points'
+        // directions stay inside it: one wave reduction instead of the whole of level 1 (the start points follow the
+        // directions, see below).  A wider set keeps a few more casters for level 2, whose first clause is cheap: headline frame
+        // 2.68 ms without, 2.60 with the set around the task's first lane (x4), 2.53 around its LAST lane (x3.5: the next tasks
+        // lie further right, so the same width reaches one task further); widths of 2, 2.5, 3, 4, 5: 2.58, 2.55, 2.57, 2.56, 2.60.
+        // (Per-component widths — the points of a row on a plane differ along one line — keep fewer casters still, but three
+        // reductions and the weighted sums cost more than that: 2.58; profiles/r03_l1_width.txt.)
+        bool reuse = false;
+        if (RT_OPT_JOBK && jk_valid && all_sane) {
+          const f3 dj = dir - jk_D0;
+          reuse = wave_max_pos(lit ? norm_inf(dj) : 0.0f) <= jk_ed;
+        }
+        if (reuse) {
+          K = jk_K; task_sph = jk_sph; task_blocked = jk_blocked;
+        } else {
+        const int jr = RT_OPT_JOBK ? 63 - __builtin_clzll(work) : __builtin_ctzll(work);
         const f3 s0 = mk(rl(start.x, jr), rl(start.y, jr), rl(start.z, jr));
         const f3 D0 = mk(rl(dir.x, jr), rl(dir.y, jr), rl(dir.z, jr));
         // One wave reduction instead of four: the points' start and dir move together (start = X + 1e-4 dir,
         // dir = light - X, kernels.cl:323-324), so |start - s0| <= (1 + 1e-4) |dir - D0| + roundings of the
         // coordinates, and |dir| lies within sqrt(3) ed of the reference point's.
         const f3 dd = dir - D0;
-        const float ed = wave_max_pos(lit ? norm_inf(dd) : 0.0f);
+        const float ed_task = wave_max_pos(lit ? norm_inf(dd) : 0.0f);
+        const float ed = RT_OPT_JOBK ? ed_task * PC(l1_inflate) : ed_task;
         const float dlen0 = rl(dlen, jr);
         const float dlen_max = (dlen0 + 1.7321f * ed) * 1.000001f;
         const float dlen_min = fmaxf(dlen0 - 1.7321f * ed, 0.0f) * 0.999999f;
         const float es = 1.0002f * ed + 2e-6f * (P.light_inf + dlen_max);
-        const bool all_sane = ballot(lit && !sane) == 0ull;
+        jk_valid = false;
         if (all_sane && es < 1e30f && ed < 1e30f) {                    // finite, non-degenerate
           const float hh_task = 1.002f * hbox + 2e-6f * (dlen_max + hbox);
           if (RT_OPT_TASKSPH && P.nsph > 0)       // every sample direction lies within sqrt(3) (ed + hh) of D0, every start within es of s0
@@ -595,6 +622,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
 #endif
           K = tri_lanes & ~ballot(tb.clear);
           task_blocked = (tri_lanes & ballot(tb.all_blocked)) != 0ull;
+          if (RT_OPT_JOBK) {
+            // what the next tasks compare with: directions within 0.9999 ed of D0 (the bound itself allows 1.001 ed and more)
+            jk_valid = true; jk_D0 = D0; jk_ed = uniform(ed * 0.9999f); jk_K = K; jk_sph = task_sph; jk_blocked = task_blocked;
+          }
+        }
         }
       }
       if (task_sph && !task_blocked && sane) sb = spheres_point(P, start, dir, dlen, hh);
