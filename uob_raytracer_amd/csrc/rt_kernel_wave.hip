@@ -598,7 +598,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
         // coordinates, and |dir| lies within sqrt(3) ed of the reference point's.
         const f3 dd = dir - D0;
         const float ed_task = wave_max_pos(lit ? norm_inf(dd) : 0.0f);
-        const float ed = RT_OPT_JOBK ? ed_task * PC(l1_inflate) : ed_task;
+        // (no wider than the tasks this job still has to come can use: its last task — and every task of a one-task job, the
+        // 16-pixel jobs of a 1024^2 frame — bounds its own set)
+        const float left = (float)(k1 - 1 - k);
+        const float ed = RT_OPT_JOBK ? ed_task * (left > 0.0f ? fminf(PC(l1_inflate), left + 0.5f) : 1.0f) : ed_task;
         const float dlen0 = rl(dlen, jr);
         const float dlen_max = (dlen0 + 1.7321f * ed) * 1.000001f;
         const float dlen_min = fmaxf(dlen0 - 1.7321f * ed, 0.0f) * 0.999999f;
