@@ -915,7 +915,7 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
         const int kq = __builtin_ctzll(kk);
         const bool part = ((mymask >> kq) & 1ull) != 0ull;
         if (ballot(part && lit && !blocked) == 0ull) continue;
-        const Bound pb = point_bound(start, dir, hh, dlen, dminlen, dk, xyz(t_v0[kq]), xyz(t_e1[kq]), xyz(t_e2[kq]), xyz(t_c[kq]));
+        const Bound pb = point_bound(start, dir, hh, dlen, dminlen, dk, xyz(t_v0[kq]), xyz(t_e1[kq]), xyz(t_e2[kq]), xyz(t_c[kq]), part && lit && !blocked);
         if (part && (!pb.clear || !sane)) need |= 1ull << kq;
         blocked = blocked || (part && sane && pb.all_blocked);
       }

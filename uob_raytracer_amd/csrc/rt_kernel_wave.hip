@@ -647,15 +647,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
         int pos = 0;
         for (unsigned long long kk = K; kk != 0ull; kk &= kk - 1ull, ++pos) {
           const int kq = __builtin_ctzll(kk);
-          {   // two thirds of the pairs that reach level 2 are a surface against its own plane: t < 0 for every
-              // sample, by the signs of det(A0) (exact) and det(A) alone — the first clause of point_bound
-            const f3 c_ = xyz(SC.c[kq]);
-            const float nA0_ = detc(start - xyz(SC.v0[kq]), c_), D0_ = detc(-dir, c_), Dl_ = hh * norm1(c_);
-            const bool tneg = sane && ((D0_ - Dl_ > 0.0f && nA0_ < -1e-18f) || (D0_ + Dl_ < 0.0f && nA0_ > 1e-18f));
-            if (ballot(lit && !tneg) == 0ull) continue;
-          }
+          // two thirds of the pairs that reach level 2 are a surface against its own plane: t < 0 for every
+          // sample, by the signs of det(A0) (exact) and det(A) alone — the first clause of point_bound
+          const f3 c_ = xyz(SC.c[kq]);
+          const float nA0_ = detc(start - xyz(SC.v0[kq]), c_), D0_ = detc(-dir, c_), Dl_ = hh * norm1(c_);
+          const bool tneg = sane && ((D0_ - Dl_ > 0.0f && nA0_ < -1e-18f) || (D0_ + Dl_ < 0.0f && nA0_ > 1e-18f));
+          if (ballot(lit && !tneg) == 0ull) continue;
           const Bound pb = point_bound(start, dir, hh, dlen, dminlen, dk, xyz(SC.v0[kq]), xyz(SC.e1[kq]), xyz(SC.e2[kq]),
-                                       xyz(SC.c[kq]));
+                                       xyz(SC.c[kq]), lit && !tneg && !blocked);
           if (!pb.clear || !sane) need |= (need_t)((need_t)1 << pos);
           blocked = blocked || (sane && pb.all_blocked);
         }
