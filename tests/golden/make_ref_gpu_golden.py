@@ -2,7 +2,7 @@
 """Generates tests/golden/ref_gfx950.npz / .json: frames rendered by THE REFERENCE ITSELF on a real OpenCL device.
 
 Runs on the GPU box (`gpurun -- python tests/golden/make_ref_gpu_golden.py`, output lands in gpurun_out/ and is copied
-to tests/golden/ by hand).  What renders the frames: /root/reference/Source/kernels.cl compiled where it lies for gfx950
+to tests/golden/ by hand; `--mesh`: the box + OBJ-mesh frames, ref_gfx950_mesh.npz / .json).  What renders the frames: /root/reference/Source/kernels.cl compiled where it lies for gfx950
 against AMD's own OpenCL builtin library with the reference's own build options (oracle/build_ref.py, code objects
 under oracle/_ref/), loaded through the OpenCL runtime and launched as skeleton.cpp launches it (oracle/ref_cl_host.c).
 No builtin, header or library is replaced by anything of ours.  The scene is the committed output of the reference's
@@ -36,6 +36,56 @@ FRAMES = {
 }
 # the headline's sample count at the headline's size (2x2 AA: the reference cannot express 4x2): crops only
 CROPS_4096 = [(1536, 2560, 512, 256), (600, 2900, 512, 192), (2304, 1100, 384, 256)]     # (x0, y0, w, h)
+
+
+# Box + OBJ mesh, the shape of the reference's main() (skeleton.cpp:102-103 appends "bunny_200.obj", a file the reference does
+# not hold: the meshes are uob_raytracer_amd/meshgen.py's, read by the product's Loader.cpp counterpart, which is pinned against
+# the reference's own loader in tests/test_scene.py).  The reference stages the whole scene in local memory (kernels.cl:374-376,
+# 80 bytes per triangle of the device's 64 KB): ~800 triangles is the most its kernel can render at all.
+#   name -> (code object, rt_config keywords, (n_lon, n_lat) of the mesh, poses)
+MESH_FRAMES = {
+    "mesh224_default":    ("default", dict(width=1024, height=1024), (16, 8), (0,)),      # the reference as shipped + a 224-triangle mesh
+    "mesh224_default256": ("default256", dict(width=256, height=256), (16, 8), (0, 1)),
+    "mesh624_cfg1":       ("cfg1", dict(width=256, height=256, aa_x=1, aa_y=1, shadow_samples=1, light_spread=0.0, spheres=()), (24, 14), (0, 1)),
+}
+
+
+def mesh_scene(lon, lat):
+    """AoS [n,5,4] of the Cornell Box + the synthetic OBJ mesh, built by the product's host code (no GPU involved)."""
+    import tempfile
+    from uob_raytracer_amd import meshgen, runtime as rt
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "m.obj")
+        meshgen.write_sphere_obj(path, lon, lat)
+        return (rt.Scene(np.load(os.path.join(HERE, "scene_cornell_aos.npy"))) + rt.Scene.load_obj(path)).aos
+
+
+def main_mesh():
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    probe = ref_gpu.probe()
+    print(json.dumps(probe), flush=True)
+    if probe.get("opencl_gpu_devices", 0) < 1:
+        sys.exit("no OpenCL GPU device on this machine")
+    arrays, meta = {}, {"probe": probe, "poses": POSES, "frames": {}}
+    for name, (variant, kw, (lon, lat), poses) in MESH_FRAMES.items():
+        aos = mesh_scene(lon, lat)
+        v, n, c = R.pack_scene(aos)
+        meta["frames"][name] = {"variant": variant, "config": kw, "mesh": [lon, lat], "triangles": int(aos.shape[0]),
+                                "scene_fnv": "%016x" % R.fnv1a64_words(np.ascontiguousarray(aos).view(np.uint32).ravel()),
+                                "poses": list(poses), "runs": {}}
+        for pi in poses:
+            yaw, pitch, cam, light = POSES[pi]
+            argb, info = ref_gpu.run(variant, kw["width"], kw["height"], v, n, c, R.rot_matrix(yaw, pitch), cam, light,
+                                     focal_for(kw), reps=2)
+            arrays["%s_p%d" % (name, pi)] = argb.reshape(kw["height"], kw["width"])
+            info["fnv_words"] = "%016x" % R.fnv1a64_words(argb)
+            meta["frames"][name]["runs"]["p%d" % pi] = info
+            print(name, pi, json.dumps(info), flush=True)
+    np.savez_compressed(os.path.join(out_dir, "ref_gfx950_mesh.npz"), **arrays)
+    with open(os.path.join(out_dir, "ref_gfx950_mesh.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print("written to", out_dir)
 
 
 def focal_for(kw):
@@ -86,4 +136,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    main_mesh() if "--mesh" in sys.argv[1:] else main()

@@ -29,6 +29,23 @@ def load():
     return meta, np.load(os.path.join(G, "ref_gfx950.npz"))
 
 
+def load_mesh():
+    """Box + OBJ-mesh frames (make_ref_gpu_golden.py --mesh): the shape of the reference's main(), skeleton.cpp:102-103."""
+    meta = json.load(open(os.path.join(G, "ref_gfx950_mesh.json")))
+    return meta, np.load(os.path.join(G, "ref_gfx950_mesh.npz"))
+
+
+def mesh_scene(lon, lat):
+    """AoS [n,5,4]: the reference's Cornell Box + uob_raytracer_amd/meshgen.py's mesh read by the product's Loader.cpp
+    counterpart (host code; tests/test_scene.py pins that loader against the reference's own)."""
+    import tempfile
+    from uob_raytracer_amd import meshgen, runtime as rt
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "m.obj")
+        meshgen.write_sphere_obj(path, lon, lat)
+        return (rt.Scene(np.load(os.path.join(G, "scene_cornell_aos.npy"))) + rt.Scene.load_obj(path)).aos
+
+
 def channels(argb):
     a = np.asarray(argb).astype(np.uint32)
     return np.stack([((a >> s) & 255).astype(np.int32) for s in (16, 8, 0)], -1)

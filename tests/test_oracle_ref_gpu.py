@@ -51,3 +51,24 @@ def test_oracle_matches_the_reference_4096_64_samples(packed, oracle):
                                 pix=pix, nthreads=8)
         st = RC.assert_within_tolerance(argb.reshape(h, w), FRAMES["s64_4096_crop%d" % i], "4096^2 window %d" % i)
         print(i, st)
+
+
+# ---- box + OBJ mesh: the scene shape of the reference's main() (skeleton.cpp:102-103), rendered by the reference on the GPU ----
+MMETA, MFRAMES = RC.load_mesh()
+MCASES = [(name, pi) for name in sorted(MMETA["frames"]) for pi in MMETA["frames"][name]["poses"]]
+
+
+@pytest.mark.parametrize("name,pi", MCASES)
+def test_oracle_matches_the_reference_on_box_plus_mesh(name, pi, oracle):
+    m = MMETA["frames"][name]
+    kw = RC.config_kwargs(m["config"])
+    aos = RC.mesh_scene(*m["mesh"])
+    assert aos.shape[0] == m["triangles"]
+    assert "%016x" % pyref.fnv1a64_words(np.ascontiguousarray(aos).view(np.uint32).ravel()) == m["scene_fnv"]      # the scene the reference rendered
+    assert m["runs"]["p%d" % pi]["device"].startswith("gfx950") and m["runs"]["p%d" % pi]["n"] == m["triangles"]
+    v, n, c = pyref.pack_scene(aos)
+    yaw, pitch, cam, light = MMETA["poses"][pi]
+    argb, _ = oracle.render(abi.make_config(**kw), v, n, c, pyref.rot_matrix(yaw, pitch), cam, light, RC.focal_for(kw), nthreads=8)
+    st = RC.assert_within_tolerance(argb.reshape(kw["height"], kw["width"]), MFRAMES["%s_p%d" % (name, pi)],
+                                    "%s pose %d" % (name, pi), general_view=(pi == 1))
+    print(name, pi, st)
