@@ -42,21 +42,22 @@ CROPS_4096 = [(1536, 2560, 512, 256), (600, 2900, 512, 192), (2304, 1100, 384, 2
 # not hold: the meshes are uob_raytracer_amd/meshgen.py's, read by the product's Loader.cpp counterpart, which is pinned against
 # the reference's own loader in tests/test_scene.py).  The reference stages the whole scene in local memory (kernels.cl:374-376,
 # 80 bytes per triangle of the device's 64 KB): ~800 triangles is the most its kernel can render at all.
-#   name -> (code object, rt_config keywords, (n_lon, n_lat) of the mesh, poses)
+#   name -> (code object, rt_config keywords, (n_lon, n_lat, wound outward?) of the mesh, poses)
 MESH_FRAMES = {
-    "mesh224_default":    ("default", dict(width=1024, height=1024), (16, 8), (0,)),      # the reference as shipped + a 224-triangle mesh
-    "mesh224_default256": ("default256", dict(width=256, height=256), (16, 8), (0, 1)),
-    "mesh624_cfg1":       ("cfg1", dict(width=256, height=256, aa_x=1, aa_y=1, shadow_samples=1, light_spread=0.0, spheres=()), (24, 14), (0, 1)),
+    "mesh224_default":    ("default", dict(width=1024, height=1024), (16, 8, 1), (0,)),      # the reference as shipped + a 224-triangle mesh
+    "mesh224_default256": ("default256", dict(width=256, height=256), (16, 8, 1), (0, 1)),
+    "mesh624_cfg1":       ("cfg1", dict(width=256, height=256, aa_x=1, aa_y=1, shadow_samples=1, light_spread=0.0, spheres=()), (24, 14, 1), (0, 1)),
+    "mesh624_inside_out": ("cfg1", dict(width=256, height=256, aa_x=1, aa_y=1, shadow_samples=1, light_spread=0.0, spheres=()), (24, 14, 0), (0,)),
 }
 
 
-def mesh_scene(lon, lat):
+def mesh_scene(lon, lat, outward=1):
     """AoS [n,5,4] of the Cornell Box + the synthetic OBJ mesh, built by the product's host code (no GPU involved)."""
     import tempfile
     from uob_raytracer_amd import meshgen, runtime as rt
     with tempfile.TemporaryDirectory() as d:
         path = os.path.join(d, "m.obj")
-        meshgen.write_sphere_obj(path, lon, lat)
+        meshgen.write_sphere_obj(path, lon, lat, outward=bool(outward))
         return (rt.Scene(np.load(os.path.join(HERE, "scene_cornell_aos.npy"))) + rt.Scene.load_obj(path)).aos
 
 
@@ -68,10 +69,10 @@ def main_mesh():
     if probe.get("opencl_gpu_devices", 0) < 1:
         sys.exit("no OpenCL GPU device on this machine")
     arrays, meta = {}, {"probe": probe, "poses": POSES, "frames": {}}
-    for name, (variant, kw, (lon, lat), poses) in MESH_FRAMES.items():
-        aos = mesh_scene(lon, lat)
+    for name, (variant, kw, (lon, lat, outw), poses) in MESH_FRAMES.items():
+        aos = mesh_scene(lon, lat, outw)
         v, n, c = R.pack_scene(aos)
-        meta["frames"][name] = {"variant": variant, "config": kw, "mesh": [lon, lat], "triangles": int(aos.shape[0]),
+        meta["frames"][name] = {"variant": variant, "config": kw, "mesh": [lon, lat, outw], "triangles": int(aos.shape[0]),
                                 "scene_fnv": "%016x" % R.fnv1a64_words(np.ascontiguousarray(aos).view(np.uint32).ravel()),
                                 "poses": list(poses), "runs": {}}
         for pi in poses:

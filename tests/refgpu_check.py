@@ -35,14 +35,14 @@ def load_mesh():
     return meta, np.load(os.path.join(G, "ref_gfx950_mesh.npz"))
 
 
-def mesh_scene(lon, lat):
+def mesh_scene(lon, lat, outward=True):
     """AoS [n,5,4]: the reference's Cornell Box + uob_raytracer_amd/meshgen.py's mesh read by the product's Loader.cpp
     counterpart (host code; tests/test_scene.py pins that loader against the reference's own)."""
     import tempfile
     from uob_raytracer_amd import meshgen, runtime as rt
     with tempfile.TemporaryDirectory() as d:
         path = os.path.join(d, "m.obj")
-        meshgen.write_sphere_obj(path, lon, lat)
+        meshgen.write_sphere_obj(path, lon, lat, outward=bool(outward))
         return (rt.Scene(np.load(os.path.join(G, "scene_cornell_aos.npy"))) + rt.Scene.load_obj(path)).aos
 
 

@@ -775,18 +775,21 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
     L.h1[lane] = make_float4(dir.x, dir.y, dir.z, 0.f);
     __builtin_amdgcn_wave_barrier();
 
+    // a point that faces away from the light (term == 0 exactly) sums +-0 whatever its samples' masks are: no shadow tests
+    // for it (rt_kernel_wave.hip) — half the surface of a closed mesh, whose rays would otherwise cross the whole mesh
+    const bool slit = lit && !(term == 0.0f);
     // ---- phase 3: shadows over all tiles ---------------------------------------------------------------
-    const unsigned long long litmask = ballot(lit);
+    const unsigned long long litmask = ballot(slit);
     const float dlen = bsqrt(radius_sq);
     const float hh = 1.002f * hbox + 2e-6f * (dlen + hbox);
     float dminlen = dlen - 1.7321f * hh;
-    const bool sane = lit && (radius_sq > 1e-18f) && (radius_sq < 1e30f);
+    const bool sane = slit && (radius_sq > 1e-18f) && (radius_sq < 1e30f);
     if (!sane || !(dminlen > 0.0f)) dminlen = 0.0f;
     const float dk = dlen * 1.000004f;
     // Level 1 bounds a SET of surface points, and is only as tight as the set is compact.  A task whose pixels
     // straddle a silhouette holds points on surfaces far apart, so the lit points are split into groups by
     // world cell (the last group takes whatever is left) and each group is bounded on its own.
-    const bool task_ok = litmask != 0ull && ballot(lit && !sane) == 0ull;
+    const bool task_ok = litmask != 0ull && ballot(slit && !sane) == 0ull;
     int ngroups = 0, grp = -1;
     bool task_sph = P.nsph > 0 && !task_ok;
     if (task_ok) {
@@ -829,7 +832,7 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
     SphereBound sb;
     sb.maybe = false; sb.all_blocked = false;
     if (task_sph && sane) sb = spheres_point(P, start, dir, dlen, hh);
-    const unsigned long long sphmask = ballot(lit && P.nsph > 0 && (sb.maybe || !sane));
+    const unsigned long long sphmask = ballot(slit && P.nsph > 0 && (sb.maybe || !sane));
     // this lane's pixel's xorshift stream after the seed call (kernels.cl:319), for the point-parallel level 3
     uint32_t rs0 = 0u, rs1 = 0u, rs2 = 0u;
     if (NS <= kPointSamples) {
@@ -847,7 +850,7 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
     for (int w = tid; w < nwords; w += 64 * kMeshWaves) smask[w] = 0ull;
     __syncthreads();
     if (litmask != 0ull) {
-      if (!bins || (PC(mask_debug) & 2) || ballot(lit && !sane) != 0ull) {
+      if (!bins || (PC(mask_debug) & 2) || ballot(slit && !sane) != 0ull) {
         for (int w = lane; w < nwords; w += 64) atomicOr(&smask[w], ~0ull);
       } else {
         const int ci = world_cell(P, start);
@@ -876,7 +879,7 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
         T1.v0 = xyz(t_v0[lane]); T1.e1 = xyz(t_e1[lane]); T1.e2 = xyz(t_e2[lane]); T1.c = xyz(t_c[lane]);
         T1.c1 = norm1(T1.c); T1.e1_1 = norm1(T1.e1); T1.e2_1 = norm1(T1.e2);
         const float v0n = norm1(T1.v0);
-        const unsigned long long alive = ballot(lit && !blocked && (my_sh & active) != active);
+        const unsigned long long alive = ballot(slit && !blocked && (my_sh & active) != active);
         K = 0ull; mymask = 0ull;
         for (int g = 0; g < ngroups; ++g) {
           const float4 g0 = L.grp[4 * g], g1 = L.grp[4 * g + 1], g2 = L.grp[4 * g + 2], g3 = L.grp[4 * g + 3];
@@ -902,7 +905,7 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
           if (grp == g) mymask = Kg;
           K |= Kg;
         }
-        if (ballot(lit && !blocked) == 0ull) { task_blocked = true; return; }
+        if (ballot(slit && !blocked) == 0ull) { task_blocked = true; return; }
       }
       MESH_STAMP(5)
       if (COUNT) { xw[2]++; xw[3] += __popcll(K); }
@@ -914,13 +917,13 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
       else for (unsigned long long kk = K; kk != 0ull; kk &= kk - 1ull) {
         const int kq = __builtin_ctzll(kk);
         const bool part = ((mymask >> kq) & 1ull) != 0ull;
-        if (ballot(part && lit && !blocked) == 0ull) continue;
-        const Bound pb = point_bound(start, dir, hh, dlen, dminlen, dk, xyz(t_v0[kq]), xyz(t_e1[kq]), xyz(t_e2[kq]), xyz(t_c[kq]), part && lit && !blocked);
+        if (ballot(part && slit && !blocked) == 0ull) continue;
+        const Bound pb = point_bound(start, dir, hh, dlen, dminlen, dk, xyz(t_v0[kq]), xyz(t_e1[kq]), xyz(t_e2[kq]), xyz(t_c[kq]), part && slit && !blocked);
         if (part && (!pb.clear || !sane)) need |= 1ull << kq;
         blocked = blocked || (part && sane && pb.all_blocked);
       }
       MESH_STAMP(6)
-      const bool mine = lit && !blocked && need != 0ull && (my_sh & active) != active;
+      const bool mine = slit && !blocked && need != 0ull && (my_sh & active) != active;
       const unsigned long long work = ballot(mine);
       if (NS <= kPointSamples) {
         // level 3 with few samples, lane = surface point: every lane runs the reference's test (kernels.cl:251-272)
@@ -1025,7 +1028,7 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
     }
     // shadow-casting spheres (kernels.cl:278-307) for the points whose rays can reach one
     {
-      const unsigned long long sw = ballot(lit && !blocked && !task_blocked && ((sphmask >> lane) & 1ull) != 0ull &&
+      const unsigned long long sw = ballot(slit && !blocked && !task_blocked && ((sphmask >> lane) & 1ull) != 0ull &&
                                            (my_sh & active) != active);
       for (int g = 0; g * GL < 64 && sw != 0ull; ++g) {
         const unsigned long long gm = (sw >> (g * GL)) & (GL == 64 ? ~0ull : ((1ull << GL) - 1ull));

@@ -550,9 +550,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
     const float radius_sq = dir.x * dir.x + dir.y * dir.y + dir.z * dir.z;
     const float term = (16.0f * fmaxf(dot3(dir, ray.N), 0.0f)) / (4.0f * 3.14159274f * radius_sq);
 
+    // A surface point that faces away from the light — term == 0: max(dot, 0) is 0 (:335) — adds (mask * 0) / (4 pi r^2) = +-0 per
+    // sample whatever its masks are, and the sum stays +0: its samples need no test at all.  (Exactly zero only: a NaN or
+    // infinite term compares unequal and takes the full path.)  Half the surface of any closed mesh, the far faces of the blocks.
+    const bool slit = lit && !(term == 0.0f);
     // ---- phase 3: shadows of the lit surface points ---------------------------------------------------
     int unshadowed = NS;                        // samples of this lnB's surface point that reach the light
-    unsigned long long work = ballot(lit);      // lanes whose samples must really be tested (level 3)
+    unsigned long long work = ballot(slit);      // lanes whose samples must really be tested (level 3)
     // need: per surface point, the casters (as positions among K's set bits) whose samples must be tested; with at most 32
     // casters (the static-layout build) it is one register, and one lane read per point in level 3
     using need_t = typename std::conditional<STRIDE == 32, uint32_t, unsigned long long>::type;
@@ -563,16 +567,16 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
       const float dlen = bsqrt(radius_sq);
       const float hh = 1.002f * hbox + 2e-6f * (dlen + hbox);
       float dminlen = dlen - 1.7321f * hh;
-      const bool sane = lit && (radius_sq > 1e-18f) && (radius_sq < 1e30f);
+      const bool sane = slit && (radius_sq > 1e-18f) && (radius_sq < 1e30f);
       if (!sane || !(dminlen > 0.0f)) dminlen = 0.0f;                  // disables the distance rule
       const float dk = dlen * 1.000004f;
-      // level 1: all lit points of the task at once, lnB = triangle
+      // level 1: all such points of the task at once, lnB = triangle
       bool task_blocked = false;
       SphereBound sb;
       sb.maybe = false; sb.all_blocked = false;
       bool task_sph = P.nsph > 0;                  // may any shadow ray of the task touch a shadow-casting sphere?
       {
-        const bool all_sane = ballot(lit && !sane) == 0ull;
+        const bool all_sane = ballot(slit && !sane) == 0ull;
         // A bound is a statement about a SET of shadow rays and holds for every subset.  The set bounded here is wider than the
         // task's own — every direction within PC(l1_inflate) x the task's spread of a reference direction — and the job's next
         // tasks (neighbouring pixels of the same row, mostly on the same surface) reuse its outcome while their points'
@@ -585,7 +589,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
         bool reuse = false;
         if (RT_OPT_JOBK && jk_valid && all_sane) {
           const f3 dj = dir - jk_D0;
-          reuse = wave_max_pos(lit ? norm_inf(dj) : 0.0f) <= jk_ed;
+          reuse = wave_max_pos(slit ? norm_inf(dj) : 0.0f) <= jk_ed;
         }
         if (reuse) {
           K = jk_K; task_sph = jk_sph; task_blocked = jk_blocked;
@@ -597,7 +601,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
         // dir = light - X, kernels.cl:323-324), so |start - s0| <= (1 + 1e-4) |dir - D0| + roundings of the
         // coordinates, and |dir| lies within sqrt(3) ed of the reference point's.
         const f3 dd = dir - D0;
-        const float ed_task = wave_max_pos(lit ? norm_inf(dd) : 0.0f);
+        const float ed_task = wave_max_pos(slit ? norm_inf(dd) : 0.0f);
         // (no wider than the tasks this job still has to come can use: its last task — and every task of a one-task job, the
         // 16-pixel jobs of a 1024^2 frame — bounds its own set)
         const float left = (float)(k1 - 1 - k);
@@ -633,7 +637,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
         }
       }
       if (task_sph && !task_blocked && sane) sb = spheres_point(P, start, dir, dlen, hh);
-      sphmask = ballot(lit && P.nsph > 0 && (sb.maybe || !sane));
+      sphmask = ballot(slit && P.nsph > 0 && (sb.maybe || !sane));
       const bool sph_blocked = sane && sb.all_blocked;
       RT_STAMP(2)                           // 2: light set-up + level 1
       if (task_blocked) {
@@ -652,15 +656,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
           const f3 c_ = xyz(SC.c[kq]);
           const float nA0_ = detc(start - xyz(SC.v0[kq]), c_), D0_ = detc(-dir, c_), Dl_ = hh * norm1(c_);
           const bool tneg = sane && ((D0_ - Dl_ > 0.0f && nA0_ < -1e-18f) || (D0_ + Dl_ < 0.0f && nA0_ > 1e-18f));
-          if (ballot(lit && !tneg) == 0ull) continue;
+          if (ballot(slit && !tneg) == 0ull) continue;
           const Bound pb = point_bound(start, dir, hh, dlen, dminlen, dk, xyz(SC.v0[kq]), xyz(SC.e1[kq]), xyz(SC.e2[kq]),
-                                       xyz(SC.c[kq]), lit && !tneg && !blocked);
+                                       xyz(SC.c[kq]), slit && !tneg && !blocked);
           if (!pb.clear || !sane) need |= (need_t)((need_t)1 << pos);
           blocked = blocked || (sane && pb.all_blocked);
         }
         if (blocked) unshadowed = 0;
-        work = ballot(lit && !blocked && (need != (need_t)0 || ((sphmask >> lnB) & 1ull) != 0ull));
-        if (COUNT) { xw.v[4] += (unsigned)__popcll(ballot(lit && !blocked && need == (need_t)0)); if (work == 0ull) xw.v[5] += 1; }
+        work = ballot(slit && !blocked && (need != (need_t)0 || ((sphmask >> lnB) & 1ull) != 0ull));
+        if (COUNT) { xw.v[4] += (unsigned)__popcll(ballot(slit && !blocked && need == (need_t)0)); if (work == 0ull) xw.v[5] += 1; }
       }
     }
 

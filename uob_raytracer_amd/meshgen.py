@@ -4,9 +4,13 @@ is not in the reference repository, so tests and benchmarks write their own mesh
 import math
 
 
-def write_sphere_obj(path, n_lon=32, n_lat=24, radius=0.13, center=(0.0, 0.25, 0.0), bumps=0.15):
+def write_sphere_obj(path, n_lon=32, n_lat=24, radius=0.13, center=(0.0, 0.25, 0.0), bumps=0.15, outward=True):
     """A bumpy UV sphere of 2*n_lon*(n_lat-1) triangles.  In OBJ space; load_obj scales by 1.5, negates and
-    translates by (-0.4, 1.15, -0.7) (Loader.cpp:42,48-52), which puts this default on the floor of the box."""
+    translates by (-0.4, 1.15, -0.7) (Loader.cpp:42,48-52), which puts this default on the floor of the box.
+    outward=True: faces wound counter-clockwise seen from outside, the OBJ convention — the loader's normals
+    (cross(e2, e1) of the negated vertices, TestModelH.h:33-37) then point out of the mesh and its light-facing side
+    is lit.  outward=False: the opposite winding (normals into the mesh, every visible point faces away from the
+    light or is in the mesh's own shadow): the orientation of this generator before round 3, kept for the tests."""
     verts = []
     for j in range(n_lat + 1):
         th = math.pi * j / n_lat
@@ -23,9 +27,9 @@ def write_sphere_obj(path, n_lon=32, n_lat=24, radius=0.13, center=(0.0, 0.25, 0
             c = a + n_lon
             d = b + n_lon
             if j > 0:
-                faces.append((a + 1, c + 1, b + 1))
+                faces.append((a + 1, b + 1, c + 1) if outward else (a + 1, c + 1, b + 1))
             if j < n_lat - 1:
-                faces.append((b + 1, c + 1, d + 1))
+                faces.append((b + 1, d + 1, c + 1) if outward else (b + 1, c + 1, d + 1))
     with open(path, "w") as f:
         f.write("# synthetic bumpy sphere: %d vertices, %d faces\n" % (len(verts), len(faces)))
         for v in verts:
