@@ -163,6 +163,12 @@ int rt_debug_trace_rays(rt_ctx* ctx, int32_t what, const float* rays6, const flo
  * RT_E_UNSUPPORTED when the context keeps no such state (n <= 64, RT_FLAG_PLAIN_ORDER, generic kernel).          */
 int rt_debug_block_costs(rt_ctx* ctx, uint32_t* out, int32_t cap);
 
+/* Diagnostic, mesh kernel (n > 64): the most recent frame's shadow-ray tile masks — for every world cell (x fastest,
+ * G x G x G cells) `words` 64-bit words, bit t = "a shadow ray that starts in this cell may hit a triangle of tile t" (tiles in
+ * the kernel's own order; a cell no surface point can start from reads 0).  Writes min(count, cap) words, returns the word
+ * count G^3 * words and stores G and words, or RT_E_UNSUPPORTED when the context builds no tile masks.                       */
+int rt_debug_world_masks(rt_ctx* ctx, uint64_t* out, int64_t cap, int32_t* grid, int32_t* words);
+
 /* Optional: let the device write the frame STRAIGHT into the caller's host framebuffer (screen->buffer,
  * SDLauxiliary.h:105) instead of rendering into device memory and copying 4 bytes per pixel back after the kernel
  * (clEnqueueReadBuffer, skeleton.cpp:179-180): the pixels cross PCIe while the frame is still being rendered.

@@ -1148,6 +1148,20 @@ int rt_debug_block_costs(rt_ctx* c, uint32_t* out, int32_t cap) {
   return jobs;
 }
 
+int rt_debug_world_masks(rt_ctx* c, uint64_t* out, int64_t cap, int32_t* grid, int32_t* words) {
+  if (!c || (!out && cap > 0) || cap < 0 || !grid || !words) { set_error("NULL argument"); return RT_E_INVALID; }
+  if (!c->kids.empty()) c = c->kids[0];
+  if (!c->d_world_masks || c->nwords <= 0) { set_error("rt_debug_world_masks: this context builds no tile masks"); return RT_E_UNSUPPORTED; }
+  DeviceGuard guard;
+  HIP_TRY(hipSetDevice(c->device));
+  if (c->timed) HIP_TRY(hipEventSynchronize(c->ev1));
+  const size_t total = (size_t)kWorldGrid * kWorldGrid * kWorldGrid * (size_t)c->nwords;
+  *grid = kWorldGrid; *words = c->nwords;
+  const size_t take = total < (size_t)cap ? total : (size_t)cap;
+  if (take > 0) HIP_TRY(hipMemcpy(out, c->d_world_masks, take * 8, hipMemcpyDeviceToHost));
+  return (int)total;
+}
+
 int rt_last_kernel_ms(rt_ctx* c, float* out_ms) {
   if (!c || !out_ms) { set_error("NULL argument"); return RT_E_INVALID; }
   DeviceGuard guard;

@@ -26,7 +26,7 @@ EXPORTS = (
     "rt_abi_version", "rt_last_error", "rt_config_default", "rt_config_owned_rows", "rt_init", "rt_render",
     "rt_render_device", "rt_count_work", "rt_count_executed", "rt_last_kernel_ms", "rt_destroy", "rt_scene_cornell_box",
     "rt_scene_load_obj", "rt_scene_load_obj_ex", "rt_triangle_compute_normal", "rt_scene_pack", "rt_rotation_matrix",
-    "rt_selftest_rcp", "rt_debug_trace_rays", "rt_debug_block_costs", "rt_debug_wave_timeline", "rt_register_output", "rt_unregister_output",
+    "rt_selftest_rcp", "rt_debug_trace_rays", "rt_debug_block_costs", "rt_debug_world_masks", "rt_debug_wave_timeline", "rt_register_output", "rt_unregister_output",
     "rt_debug_band_copy_plan",
 )
 
@@ -65,6 +65,7 @@ def lib():
         L.rt_scene_load_obj_ex.argtypes = [C.c_char_p, fp, C.c_float, fp, C.POINTER(abi.RtTriangle), C.c_int32]
         L.rt_debug_trace_rays.argtypes = [vp, C.c_int32, fp, fp, C.c_int64, C.POINTER(C.c_int32), fp]
         L.rt_debug_block_costs.argtypes = [vp, C.POINTER(C.c_uint32), C.c_int32]
+        L.rt_debug_world_masks.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.rt_debug_wave_timeline.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.rt_debug_band_copy_plan.argtypes = [C.c_int32] * 9 + [C.POINTER(abi.RtBandCopy), C.c_int32]
         L.rt_register_output.argtypes = [vp, vp, C.c_size_t]
@@ -273,6 +274,14 @@ class RayTracer:
         first, last = int(out[1]), int(out[2])
         return {"waves": int(out[0]), "span_us": (last - first) / 100.0, "mean_start_us": (int(out[3]) / n - first) / 100.0,
                 "mean_idle_tail_us": (last - int(out[4]) / n) / 100.0, "jobs": int(out[5]), "max_jobs_per_wave": int(out[6]), "listed_jobs": int(out[7])}
+
+    def world_masks(self):
+        """Mesh kernel: the last frame's shadow-ray tile masks, uint64 [G, G, G, words] indexed [z, y, x] (rt_debug_world_masks)."""
+        g, w = C.c_int32(), C.c_int32()
+        n = _check(lib().rt_debug_world_masks(self._h, None, 0, C.byref(g), C.byref(w)))
+        out = np.zeros(n, np.uint64)
+        _check(lib().rt_debug_world_masks(self._h, out.ctypes.data_as(C.POINTER(C.c_uint64)), n, C.byref(g), C.byref(w)))
+        return out.reshape(g.value, g.value, g.value, w.value)
 
     def block_costs(self):
         """Mesh kernel: s_memtime ticks of every 16x16-pixel block of the last frame, [rows/16, W/16] (rt_debug_block_costs)."""
