@@ -24,11 +24,6 @@ __device__ __forceinline__ f3 xyz(float4 v) { return f3{v.x, v.y, v.z}; }
 // OpenCL dot as the oracle defines it: x*x + y*y + z*z, left to right
 __device__ __forceinline__ float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 // OpenCL normalize as the oracle defines it: v / sqrtf(dot(v,v))
-__device__ __forceinline__ f3 normalize3(f3 a) {
-  const float len = sqrtf(a.x * a.x + a.y * a.y + a.z * a.z);
-  return f3{a.x / len, a.y / len, a.z / len};
-}
-
 // The 2x2 cofactors of rows (m1, m2) used by det (kernels.cl:31-35):
 //   det(m0,m1,m2) = m0.x*c.x - m0.y*c.y + m0.z*c.z   with c = cof(m1,m2)
 __device__ __forceinline__ f3 cof(f3 m1, f3 m2) {
@@ -61,6 +56,36 @@ __device__ __forceinline__ float rcp_exact(float x) {
   }
   return r;
 }
+
+// normalize(): a / sqrt(a.a), the square root and the three quotients correctly rounded (the oracle's normalize3, strict C).
+// IEEE sqrt + three IEEE divisions are ~160 issue cycles on this GPU; the same bits come from
+//   len = v_rsq_f32 refined once in FMA arithmetic   (== sqrtf(x) for EVERY x in [2^-60, 2^60]: tools/sqrt_check.hip, all 2^32 patterns)
+//   r   = RN(1 / len)                                 (rcp_newton, exact for every normal len: rt_selftest_rcp)
+//   q0 = a * r,  e = fma(-len, q0, a),  q = fma(e, r, q0)      (== a / len for EVERY pair of significands: tools/div_check.hip, all 2^46
+//        pairs, no mismatch — every step scales with the exponents, so the check holds wherever nothing under- or overflows:
+//        len in [2^-30, 2^30], |q0| in [2^-30, 1], the residual e then a normal number or exactly 0)
+// in ~70.  Anything else — a zero or tiny component, a NaN, a vector shorter than 2^-30 or longer than 2^30 — takes the IEEE
+// operations behind a wave-uniform branch, as rcp_exact does.
+__device__ __forceinline__ f3 normalize3(f3 a) {
+  const float x = a.x * a.x + a.y * a.y + a.z * a.z;
+  const float y = __builtin_amdgcn_rsqf(x);
+  const float s = x * y, h = 0.5f * y;
+  const float len = __builtin_fmaf(__builtin_fmaf(-s, s, x), h, s);
+  const float r = rcp_newton(len, 1);
+  const float q0x = a.x * r, q0y = a.y * r, q0z = a.z * r;
+  f3 q = f3{__builtin_fmaf(__builtin_fmaf(-len, q0x, a.x), r, q0x), __builtin_fmaf(__builtin_fmaf(-len, q0y, a.y), r, q0y),
+            __builtin_fmaf(__builtin_fmaf(-len, q0z, a.z), r, q0z)};
+  const float mn = fminf(fminf(fabsf(q0x), fabsf(q0y)), fabsf(q0z));
+  const bool ok = x >= 0x1p-60f && x <= 0x1p60f && mn >= 0x1p-30f;        // (false for NaN)
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0ull, 0)) {
+    if (!ok) {
+      const float l2 = sqrtf(x);
+      q = f3{a.x / l2, a.y / l2, a.z / l2};
+    }
+  }
+  return q;
+}
+
 
 // x / (float)n for a wave-uniform count n (kernels.cl:338 total / light_sources, :426 final / aa_rays).  When n is a
 // power of two the host passes inv = 1/n (exact) and the quotient is the product: both are the correctly rounded
