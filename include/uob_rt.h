@@ -214,6 +214,13 @@ int rt_debug_band_copy_plan(int32_t num_devices, int32_t k, int32_t device_band_
  * the remaining finite non-zero x; out[4] = examples recorded; out[8..63] = mismatching bit patterns.   */
 int rt_selftest_rcp(uint64_t out[64]);
 
+/* On-device self test of normalize()'s building blocks (rt_math.h normalize3): (a) v_rsq_f32 refined once against the
+ * correctly rounded sqrtf for every FP32 pattern in [2^-60, 2^60]; (b) the quotient q = fma(fma(-b, a r, a), r, a r) from the
+ * exact reciprocal r of b against the correctly rounded a / b for EVERY significand of a and every b_stride-th significand
+ * of b (b_stride = 1: all 2^46 pairs, about half a minute; tools/div_check.hip is the same sweep as a program).
+ * out[0] mismatches of (a), out[1] mismatches of (b), out[2] pairs checked by (b), out[3] / out[4] a mismatching pattern each. */
+int rt_selftest_normalize(uint64_t out[8], uint32_t b_stride);
+
 void rt_destroy(rt_ctx* ctx);
 /* Message of the last failure on the calling thread.  After an RT_OK from rt_init / rt_render_device of a multi-device
  * context it may instead hold a line that starts with "warning:" — a device without peer access to the root device

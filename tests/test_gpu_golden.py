@@ -142,6 +142,35 @@ def test_exact_reciprocal_selftest():
     assert r["edge_mismatch_1step"] <= 2 * (1 << 23) + 4 * (1 << 23)   # denormals + two top binades, both signs
 
 
+def test_normalize_building_blocks_selftest():
+    """normalize3 (rt_math.h): the refined v_rsq_f32 == sqrtf for every pattern in [2^-60, 2^60], and the quotient from the
+    shared exact reciprocal == a / b for every significand of a against every 97th significand of b (8.6e4 x 8.4e6 pairs
+    here; all 2^46 pairs with tools/div_check.hip / rt_selftest_normalize(out, 1): no mismatch, profiles/README.md)."""
+    r = rt.selftest_normalize(97)
+    assert r["sqrt_mismatches"] == 0, hex(r["sqrt_example"])
+    assert r["div_mismatches"] == 0, hex(r["div_example"])
+    assert r["div_pairs"] >= (1 << 23) * ((1 << 23) // 97)
+
+
+def test_normalize_zero_components_take_the_ieee_path(scene, oracle):
+    """An odd frame width at the identity rotation: the rays of the centre column have dir.x == 0 exactly, the centre row's
+    dir.y == 0 — components outside normalize3's checked range, which take the IEEE square root and divisions behind its
+    wave-uniform branch.  Identical to the oracle either way (the wide-domain cases of test_gpu_thresholds.py cover the
+    scales at which whole vectors leave the range)."""
+    kw = dict(width=65, height=33, aa_x=1, aa_y=1, shadow_samples=3)
+    cfg = abi.make_config(**kw)
+    v, n, c = scene.packed()
+    rot = rt.rotation_matrix(0.0, 0.0)
+    cam, light = [0.0, 0.0, -3.2], [0.0, -0.5, -0.7]
+    for flags in (0, abi.RT_FLAG_GENERIC_KERNEL):
+        tr = rt.RayTracer(abi.make_config(flags=flags, **kw), scene)
+        argb, rgb = tr.render(rot, cam, light, focal_for(kw), want_rgb=True)
+        tr.close()
+        o_argb, o_rgb = oracle.render(cfg, v, n, c, rot, cam, light, focal_for(kw))
+        assert np.array_equal(argb.ravel(), o_argb)
+        assert np.array_equal(rgb[..., :3].reshape(-1, 3).view(np.uint32), o_rgb.view(np.uint32))
+
+
 def test_work_counters_match_oracle(scene, oracle):
     kw = dict(width=96, height=64, shadow_samples=5)
     yaw, pitch, cam, light = POSES[1]

@@ -26,7 +26,7 @@ EXPORTS = (
     "rt_abi_version", "rt_last_error", "rt_config_default", "rt_config_owned_rows", "rt_init", "rt_render",
     "rt_render_device", "rt_count_work", "rt_count_executed", "rt_last_kernel_ms", "rt_destroy", "rt_scene_cornell_box",
     "rt_scene_load_obj", "rt_scene_load_obj_ex", "rt_triangle_compute_normal", "rt_scene_pack", "rt_rotation_matrix",
-    "rt_selftest_rcp", "rt_debug_trace_rays", "rt_debug_block_costs", "rt_debug_world_masks", "rt_debug_wave_timeline", "rt_register_output", "rt_unregister_output",
+    "rt_selftest_rcp", "rt_selftest_normalize", "rt_debug_trace_rays", "rt_debug_block_costs", "rt_debug_world_masks", "rt_debug_wave_timeline", "rt_register_output", "rt_unregister_output",
     "rt_debug_band_copy_plan",
 )
 
@@ -109,6 +109,15 @@ def selftest_rcp():
     v = list(out)
     return {"safe_mismatch_1step": v[0], "safe_mismatch_2step": v[1], "edge_mismatch_1step": v[2],
             "edge_mismatch_2step": v[3], "examples": [int(b) & 0xFFFFFFFF for b in v[8:8 + min(v[4], 56)]]}
+
+
+def selftest_normalize(b_stride=64):
+    """normalize()'s square root over every FP32 pattern and its quotients over every significand of a and every
+    b_stride-th significand of b (include/uob_rt.h rt_selftest_normalize)."""
+    out = (C.c_uint64 * 8)()
+    _check(lib().rt_selftest_normalize(out, C.c_uint32(b_stride)))
+    v = list(out)
+    return {"sqrt_mismatches": v[0], "div_mismatches": v[1], "div_pairs": v[2], "sqrt_example": v[3], "div_example": v[4]}
 
 
 def default_config():
