@@ -229,6 +229,95 @@ __device__ __forceinline__ Count2 wave_unshadowed_pair(const FrameParams& P, con
   return r;
 }
 
+// Level 3 for FEW samples (NS <= 32): with lane = sample a pass of wave_unshadowed_pair keeps NS of 64 lanes busy.  Here a lane
+// is a (surface point, sample): SP = 16 or 32 sample slots per point (the slots >= NS idle), 64 / SP points per instance, and
+// two independent instances a / b per pass as before (the dependent chain LDS record -> determinants -> reciprocal -> compares
+// needs a second one to interleave with) — 8 points per pass at up to 16 samples, 4 at up to 32, instead of 2.  An instance's
+// points belong to ONE pixel (they share its jitter stream `rng`: word 4 s + component of sample s); pm = their lanes, bit i =
+// lane base + i.  Every lane tests the casters any point of its pass needs (testing a triangle a point does not need cannot
+// produce a hit for it).  `unshadowed` of the points' own lanes receives the counts.
+template <int SP>
+__device__ __forceinline__ void wave_unshadowed_packed(const FrameParams& P, const ShadowCasters& SC, const WaveLds& L, int lane,
+                                                       unsigned long long pmA, int baseA, const uint32_t* rngA,
+                                                       unsigned long long pmB, int baseB, const uint32_t* rngB,
+                                                       unsigned long long K, unsigned long long need_l, unsigned long long sphmask,
+                                                       int NS, int& unshadowed) {
+  constexpr int PK = 64 / SP;
+  const int q = lane / SP, sidx = lane - q * SP;
+  int ja[PK], jb[PK];
+  {
+    unsigned long long m = pmA;
+#pragma unroll
+    for (int i = 0; i < PK; ++i) { ja[i] = m != 0ull ? baseA + __builtin_ctzll(m) : -1; m &= m - 1ull; }
+    m = pmB;
+#pragma unroll
+    for (int i = 0; i < PK; ++i) { jb[i] = m != 0ull ? baseB + __builtin_ctzll(m) : -1; m &= m - 1ull; }
+  }
+  int myA = ja[0], myB = jb[0];
+#pragma unroll
+  for (int i = 1; i < PK; ++i) { myA = q == i ? ja[i] : myA; myB = q == i ? jb[i] : myB; }
+  const bool actA = myA >= 0 && sidx < NS, actB = myB >= 0 && sidx < NS;
+  unsigned long long need = 0ull;
+#pragma unroll
+  for (int i = 0; i < PK; ++i) {
+    if (ja[i] >= 0) need |= ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(need_l >> 32), ja[i]) << 32) | (unsigned)__builtin_amdgcn_readlane((int)need_l, ja[i]);
+    if (jb[i] >= 0) need |= ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(need_l >> 32), jb[i]) << 32) | (unsigned)__builtin_amdgcn_readlane((int)need_l, jb[i]);
+  }
+  const float4 ha0 = L.h0[actA ? myA : 0], ha1 = L.h1[actA ? myA : 0], hb0 = L.h0[actB ? myB : 0], hb1 = L.h1[actB ? myB : 0];
+  const f3 sa = mk(ha0.x, ha0.y, ha0.z), sb = mk(hb0.x, hb0.y, hb0.z);
+  const float ra = ha0.w, rb = hb0.w;
+  const int sw = (sidx < NS ? sidx : 0) * 4;
+  const f3 jitA = mk(crush1(rngA[sw], P.spread), crush1(rngA[sw + 1], P.spread), crush1(rngA[sw + 2], P.spread));
+  const f3 jitB = mk(crush1(rngB[sw], P.spread), crush1(rngB[sw + 1], P.spread), crush1(rngB[sw + 2], P.spread));
+  const f3 da = mk(ha1.x, ha1.y, ha1.z) + jitA, db = mk(hb1.x, hb1.y, hb1.z) + jitB;   // dir + crush(...), :333
+  const f3 nda = -da, ndb = -db;
+  bool blkA = false, blkB = false;
+  int pos = 0;
+  for (unsigned long long kk = K; kk != 0ull; kk &= kk - 1ull, ++pos) {
+    if (((need >> pos) & 1ull) == 0ull) continue;
+    const int k = __builtin_ctzll(kk);
+    const f3 v0 = xyz(SC.v0[k]), e1 = xyz(SC.e1[k]), e2 = xyz(SC.e2[k]), c = xyz(SC.c[k]);
+    // first stage, :251-266 (negated compares: also true for NaN, see rcp_newton)
+    const f3 ba = sa - v0, bb = sb - v0;
+    const float nA0a = detc(ba, c), nA0b = detc(bb, c);
+    const float detAa = detc(nda, c), detAb = detc(ndb, c);
+    float rra = rcp_newton(detAa, 1), rrb = rcp_newton(detAb, 1);
+    float ta = nA0a * rra, tb = nA0b * rrb;
+    f3 dva = ta * da, dvb = tb * db;
+    float dista = dva.x * dva.x + dva.y * dva.y + dva.z * dva.z;
+    float distb = dvb.x * dvb.x + dvb.y * dvb.y + dvb.z * dvb.z;
+    bool passa = !(ta < 0.0f) && !(dista >= ra), passb = !(tb < 0.0f) && !(distb >= rb);
+    if (ballot((actA && !blkA && passa) || (actB && !blkB && passb)) == 0ull) continue;
+    if (ballot((actA && rra != rra) || (actB && rrb != rrb)) != 0ull) {        // rare: reciprocal outside v_rcp's range
+      rra = 1.0f / detAa; rrb = 1.0f / detAb;
+      ta = nA0a * rra; tb = nA0b * rrb;
+      dva = ta * da; dvb = tb * db;
+      dista = dva.x * dva.x + dva.y * dva.y + dva.z * dva.z;
+      distb = dvb.x * dvb.x + dvb.y * dvb.y + dvb.z * dvb.z;
+      passa = ta >= 0 && dista < ra; passb = tb >= 0 && distb < rb;
+    }
+    // second stage, :268-272
+    const float ua = detc(nda, cof(ba, e2)) * rra, va = detc(nda, cof(e1, ba)) * rra;
+    const float ub = detc(ndb, cof(bb, e2)) * rrb, vb = detc(ndb, cof(e1, bb)) * rrb;
+    blkA = blkA || (passa && ua >= 0 && va >= 0 && (ua + va) <= 1);
+    blkB = blkB || (passb && ub >= 0 && vb >= 0 && (ub + vb) <= 1);
+    if (ballot((actA && !blkA) || (actB && !blkB)) == 0ull) break;          // every sample of every point blocked
+  }
+  const bool sphA = actA && ((sphmask >> (myA >= 0 ? myA : 0)) & 1ull) != 0ull, sphB = actB && ((sphmask >> (myB >= 0 ? myB : 0)) & 1ull) != 0ull;
+  if (ballot((sphA && !blkA) || (sphB && !blkB)) != 0ull) {
+    Work unused;
+    if (sphA && !blkA) blkA = shadow_spheres<false>(P, sa, da, ra, unused);
+    if (sphB && !blkB) blkB = shadow_spheres<false>(P, sb, db, rb, unused);
+  }
+  const unsigned long long mA = ballot(actA && !blkA), mB = ballot(actB && !blkB);      // samples that reach the light
+#pragma unroll
+  for (int i = 0; i < PK; ++i) {
+    if (jb[i] >= 0 && lane == jb[i]) unshadowed = __popcll((mB >> (i * SP)) & ((1ull << SP) - 1ull));
+    if (ja[i] >= 0 && lane == ja[i]) unshadowed = __popcll((mA >> (i * SP)) & ((1ull << SP) - 1ull));
+  }
+}
+
+
 }  // namespace
 
 // Persistent waves: the grid is what fits the chip at once (CUs x RT_MIN_WAVES workgroups of 4 waves); each
@@ -709,6 +798,28 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       RT_STAMP(4)                           // 4: xorshift streams
+      if (CULL && !COUNT && !MULTI && SS > 0 && SS <= 32) {
+        // few samples: lane = (surface point, sample), 64 / SP points of one pixel per instance, two instances per pass
+        constexpr int SP = (SS > 0 && SS <= 16) ? 16 : 32, PK = 64 / SP;
+        const unsigned long long aam = aa == 64 ? ~0ull : ((1ull << aa) - 1ull);
+        unsigned long long rest = gm;
+        while (rest != 0ull) {
+          unsigned long long pmv[2] = {0ull, 0ull};
+          int basev[2] = {0, 0}, ppv[2] = {0, 0};
+#pragma unroll
+          for (int inst = 0; inst < 2; ++inst) {
+            if (rest == 0ull) break;
+            const int b0 = __builtin_ctzll(rest);
+            const int pp = (b0 * (aa == 1 ? 65536 : P.aa_magic)) >> 16;     // b0 / aa (b0 < 64)
+            unsigned long long pm = (rest >> (pp * aa)) & aam, take = 0ull;
+            for (int i = 0; i < PK && pm != 0ull; ++i) { take |= pm & (0ull - pm); pm &= pm - 1ull; }   // its lowest PK points
+            pmv[inst] = take; basev[inst] = g * GL + pp * aa; ppv[inst] = pp;
+            rest &= ~(take << (pp * aa));
+          }
+          wave_unshadowed_packed<SP>(P, SC, L, lnC, pmv[0], basev[0], L.rng + ppv[0] * kRngStride, pmv[1], basev[1],
+                                     L.rng + ppv[1] * kRngStride, K, (unsigned long long)need, sphmask, NS, unshadowed);
+        }
+      } else
       for (int pp = 0; pp < GP; ++pp) {
         unsigned long long pm = (gm >> (pp * aa)) & (aa == 64 ? ~0ull : ((1ull << aa) - 1ull));
         if (pm == 0ull) continue;
