@@ -432,9 +432,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
   Work wk, xw;                               // xw: executed-work counters of this wave (COUNT builds only)
   if (COUNT) for (int q = 0; q < 8; ++q) xw.v[q] = 0;
   // ---- job loop.  The queue has kJobHeads heads; a wave pulls from its home head until that one's jobs are
-  // gone, then walks on through the others (peeking with a load before spending an atomic), and leaves after a
-  // full round: every head only grows, so every wave reaches the exit.
-  int head = (int)((blockIdx.x * kWavesPerBlock + wave) % kJobHeads), heads_done = 0;
+  // gone, then moves on to the next head that still has jobs (all heads peeked at with one load), and leaves when
+  // none has: every head only grows, so every wave reaches the exit.
+  int head = (int)((blockIdx.x * kWavesPerBlock + wave) % kJobHeads);
   // Longest jobs first: the jobs that cost more than heavy_factor4/4 x the average in the previous frame of this context
   // are pulled (phase A, second set of heads) before the plain sequence (phase B, which skips them by their flag).
   // (Handing the expensive jobs out one TASK at a time, to different waves, was built and measured: no gain at 512 rows
@@ -504,14 +504,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
       chunk = left > 2 * per_wave ? RT_CHUNK : (left > per_wave ? 2 : 1);
     }
     if (job >= PC(njobs)) {
+      // This head is empty: look at ALL heads at once (lane h reads head h: one memory round trip, not one per head — walking
+      // them one by one kept every wave ~30 us in the kernel after its last job, a fifth of a 1024^2 frame) and move on to the
+      // next one that still has jobs; none: leave.  The heads only grow, so what is empty stays empty: every wave gets here.
       chunk_left = 0;
-      bool found = false;
-      while (!found && ++heads_done < kJobHeads) {
-        head = head + 1 == kJobHeads ? 0 : head + 1;
-        const unsigned int at = __hip_atomic_load(PC(job_counter) + head * kJobHeadStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        found = (long long)at * kJobHeads + head < (long long)PC(njobs);
-      }
-      if (!found) break;
+      const unsigned int at = lane < kJobHeads ? __hip_atomic_load(PC(job_counter) + lane * kJobHeadStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+      const unsigned long long avail = ballot(lane < kJobHeads && (long long)at * kJobHeads + lane < (long long)PC(njobs));
+      if (avail == 0ull) break;
+      const unsigned long long above = avail & ~((2ull << head) - 1ull);            // cyclically after this head
+      head = __builtin_ctzll(above != 0ull ? above : avail);
       continue;
     }
     if ((listed & 1u) != 0u) continue;                                    // listed: taken care of by phase A
