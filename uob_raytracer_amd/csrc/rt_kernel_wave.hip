@@ -799,9 +799,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, RT_MIN_WAVES) void rt_draw_wav
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       RT_STAMP(4)                           // 4: xorshift streams
-      if (CULL && !COUNT && !MULTI && SS > 0 && SS <= 32) {
+      if (CULL && !COUNT && !MULTI && ((SS > 0 && SS <= 32) || (SS == 0 && STRIDE == 32 && !BIGAA && NS <= 16))) {
         // few samples: lane = (surface point, sample), 64 / SP points of one pixel per instance, two instances per pass
-        constexpr int SP = (SS > 0 && SS <= 16) ? 16 : 32, PK = 64 / SP;
+        // (the instantiations specialised on the sample count; the static-layout generic one for up to 16 samples)
+        constexpr int SP = (SS > 16) ? 32 : 16, PK = 64 / SP;
         const unsigned long long aam = aa == 64 ? ~0ull : ((1ull << aa) - 1ull);
         unsigned long long rest = gm;
         while (rest != 0ull) {
