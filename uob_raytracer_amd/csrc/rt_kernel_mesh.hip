@@ -262,9 +262,17 @@ __host__ __device__ inline int occ_words(int G) { return occ_offset(G, 2) + ((G 
 // a sphere, and its start point X + 1e-4 (light - X) within 1e-4 |light - X| of it.  One thread per triangle (then
 // per sphere) marks the cells its bounding box touches, widened by that distance, by the rounding of world_cell()
 // and by 1 % of a cell; rt_bin_shadow skips every other cell (no task ever reads their masks).
-__global__ __launch_bounds__(256) void rt_bin_occupancy(const FrameParams P) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+// (A mesh puts tens of thousands of triangles into a few dozen cells: every workgroup ORs into a copy of the three bitmaps in
+// LDS and sends what it has set to memory once — atomics on one address are serialised memory-side, and with one per wave and
+// word the kernel spent 0.46 ms of configs[4]'s frame on them.)
+constexpr int kOccThreads = 1024;
+__global__ __launch_bounds__(kOccThreads) void rt_bin_occupancy(const FrameParams P) {
+  extern __shared__ unsigned int s_occ[];
+  const int i = blockIdx.x * kOccThreads + threadIdx.x;
   const int G = P.grid_g;
+  const int n_occ_words = occ_words(G);
+  for (int w = threadIdx.x; w < n_occ_words; w += kOccThreads) s_occ[w] = 0u;
+  __syncthreads();
   f3 lo, hi;
   if (i < P.n) {
     const f3 a0 = xyz(P.records[i]), a1 = a0 + xyz(P.records[(size_t)P.n + i]), a2 = a0 + xyz(P.records[(size_t)2 * P.n + i]);
@@ -307,7 +315,7 @@ __global__ __launch_bounds__(256) void rt_bin_occupancy(const FrameParams P) {
   const bool single = valid && c0[0] == c1[0] && c0[1] == c1[1] && c0[2] == c1[2];
   for (int level = 0; level < 3; ++level) {
     const int g = G >> level;
-    unsigned int* occ = P.world_occ + occ_offset(G, level);
+    unsigned int* occ = s_occ + occ_offset(G, level);
     const int cell = (((c0[2] >> level) * g + (c0[1] >> level)) * g + (c0[0] >> level));
     const int word = single ? (cell >> 5) : -1;
     const unsigned int bit = single ? (1u << (cell & 31)) : 0u;
@@ -330,6 +338,11 @@ __global__ __launch_bounds__(256) void rt_bin_occupancy(const FrameParams P) {
             atomicOr(&occ[w], m);
           }
         }
+  }
+  __syncthreads();
+  for (int w = threadIdx.x; w < n_occ_words; w += kOccThreads) {
+    const unsigned int m = s_occ[w];
+    if (m != 0u) atomicOr(&P.world_occ[w], m);
   }
 }
 
@@ -1204,7 +1217,7 @@ void launch_mesh(const FrameParams& P, bool count, bool prof, hipStream_t stream
                       hipEventRecord(ev_fork, stream) == hipSuccess && hipStreamWaitEvent(aux, ev_fork, 0) == hipSuccess;
     hipLaunchKernelGGL(rt_bin_primary, dim3((ntiles + kMeshWaves - 1) / kMeshWaves, P.scy), block, 0, fork ? aux : stream, P);
     if (fork) hipEventRecord(ev_join, aux);
-    hipLaunchKernelGGL(rt_bin_occupancy, dim3((P.n + P.nsph + 255) / 256), dim3(256), 0, stream, P);
+    hipLaunchKernelGGL(rt_bin_occupancy, dim3((P.n + P.nsph + kOccThreads - 1) / kOccThreads), dim3(kOccThreads), (size_t)occ_words(P.grid_g) * sizeof(unsigned int), stream, P);
     hipLaunchKernelGGL(rt_bin_shadow, dim3((ntiles + kMeshWaves - 1) / kMeshWaves, P.grid_g / 4, P.grid_g / 4), block, 0, stream, P);
     if (fork) hipStreamWaitEvent(stream, ev_join, 0);
   }
