@@ -106,7 +106,7 @@ struct FrameParams {
   unsigned int* world_occ;            // bitmaps of the world cells that can hold a surface point: G^3, (G/2)^3, (G/4)^3 bits
   int32_t mask_debug;                 // diagnostic (UOB_RT_MASK_DEBUG): 1 = ignore screen masks, 2 = ignore world masks, 4 = every world cell occupied,
                                       // 8 = every block of the next frame cooperative (tests), 16 = a context's first frame in row order (no cost guess),
-                                      // 64 = bounce rays visit every tile (no tile pre-test)
+                                      // 64 = bounce rays visit every tile (no tile pre-test), 256 = shadow-ray masks without the tile-level certificate
   int32_t nwords, scx, scy, grid_g;   // 64-bit words per mask; screen cells per row / column; world cells per axis
   float grid_lo[3], grid_cell, grid_inv;   // world grid: origin, cell edge, 1 / cell edge
 };

@@ -393,15 +393,44 @@ __global__ __launch_bounds__(64 * kMeshWaves) void rt_bin_shadow(const FramePara
     return mk(P.grid_lo[0] + ((float)ix + 0.5f) * edge, P.grid_lo[1] + ((float)iy + 0.5f) * edge, P.grid_lo[2] + ((float)iz + 0.5f) * edge);
   };
   const int Gq = G >> 2, izq = blockIdx.z, iyq = blockIdx.y;         // one row of coarsest cells per wave
+  // Where the coarse cell's own bundle is not clear, the tile as a whole is asked next, lane = one of the coarse cell's
+  // 4 x 4 x 4 single cells: the bounce rays' tile certificate (tile_clear_for_bundle: box, normal cone and sliver measure of
+  // the tile) for each single cell's bundle — start points C +- hs, directions (light - C) +- (ed + jitter half-width).  It
+  // reasons differently from the per-triangle intervals (a separating plane through the ray instead of the signs of the
+  // determinants), so it clears (tile, cell) pairs the hierarchy below cannot: 6 % fewer tiles per cell on configs[4].
+  const bool tile_test = PC(tile_box) != nullptr && !(P.mask_debug & 256);
   for (int ixq = 0; ixq < Gq; ++ixq) {
       if (!occupied(P, 2, ixq, iyq, izq)) continue;
       if (ballot(ok && !cell_clear(centre(ixq, iyq, izq, 4.0f * P.grid_cell), 4.0f * half)) == 0ull) continue;
+      unsigned long long open = ~0ull;                                 // single cells (bit = 16 dz + 4 dy + dx) still to be decided
+      if (tile_test) {
+        const int dx = lane & 3, dy = (lane >> 2) & 3, dz = lane >> 4;
+        const int ix = 4 * ixq + dx, iy = 4 * iyq + dy, iz = 4 * izq + dz;
+        bool want = occupied(P, 0, ix, iy, iz);
+        if (want) {
+          const f3 C = centre(ix, iy, iz, P.grid_cell);
+          const float cinf = norm_inf(C);
+          const float hs = 1.001f * half + 1e-5f * (1.0f + cinf);
+          const f3 D0 = light - C;
+          const float d0len = bsqrt(dot3(D0, D0));
+          const float ed = hs + 1.1e-4f * (d0len + 2.0f * hs) + 1e-6f * (1.0f + norm_inf(D0) + cinf);
+          const float dlen_max = (d0len + 1.7321f * ed) * 1.00001f;
+          const float hh = 1.002f * hbox + 2e-6f * (dlen_max + hbox);
+          want = !tile_clear_for_bundle(PC(tile_box) + (size_t)3 * t, C, D0, hs, ed * 1.0001f + hh, (dlen_max + 1.7321f * hh) * 1.0001f);
+        }
+        open = ballot(want);
+        if (open == 0ull) continue;
+      }
       for (int s2 = 0; s2 < 8; ++s2) {
         const int ixc = 2 * ixq + (s2 & 1), iyc = 2 * iyq + ((s2 >> 1) & 1), izc = 2 * izq + (s2 >> 2);
         if (!occupied(P, 1, ixc, iyc, izc)) continue;
+        // (its eight single cells: dx in {2 (s2&1), +1}, ...)
+        const unsigned long long sub_bits = 0x0000000000330033ull << (2 * (s2 & 1) + 8 * ((s2 >> 1) & 1) + 32 * (s2 >> 2));
+        if ((open & sub_bits) == 0ull) continue;
         if (ballot(ok && !cell_clear(centre(ixc, iyc, izc, 2.0f * P.grid_cell), 2.0f * half)) == 0ull) continue;
         for (int sub = 0; sub < 8; ++sub) {
           const int ix = 2 * ixc + (sub & 1), iy = 2 * iyc + ((sub >> 1) & 1), iz = 2 * izc + (sub >> 2);
+          if (((open >> (((iz & 3) << 4) | ((iy & 3) << 2) | (ix & 3))) & 1ull) == 0ull) continue;      // (unoccupied, or the tile test settled it)
           if (!occupied(P, 0, ix, iy, iz)) continue;
           const unsigned long long m = ballot(ok && !cell_clear(centre(ix, iy, iz, P.grid_cell), half));
           if (m != 0ull && lane == 0)
