@@ -402,12 +402,14 @@ __global__ __launch_bounds__(64 * kMeshWaves) void rt_bin_shadow(const FramePara
   for (int ixq = 0; ixq < Gq; ++ixq) {
       if (!occupied(P, 2, ixq, iyq, izq)) continue;
       if (ballot(ok && !cell_clear(centre(ixq, iyq, izq, 4.0f * P.grid_cell), 4.0f * half)) == 0ull) continue;
-      unsigned long long open = ~0ull;                                 // single cells (bit = 16 dz + 4 dy + dx) still to be decided
-      if (tile_test) {
+      // single cells (bit = 16 dz + 4 dy + dx) still to be decided: the occupied ones (all 64 looked up at once, lane = cell —
+      // a block of cells is occupied exactly if one of its cells is, so the loops below need no further look-ups) ...
+      unsigned long long open;
+      {
         const int dx = lane & 3, dy = (lane >> 2) & 3, dz = lane >> 4;
         const int ix = 4 * ixq + dx, iy = 4 * iyq + dy, iz = 4 * izq + dz;
         bool want = occupied(P, 0, ix, iy, iz);
-        if (want) {
+        if (tile_test && want) {                                        // ... that the tile as a whole is not clear of
           const f3 C = centre(ix, iy, iz, P.grid_cell);
           const float cinf = norm_inf(C);
           const float hs = 1.001f * half + 1e-5f * (1.0f + cinf);
@@ -423,15 +425,16 @@ __global__ __launch_bounds__(64 * kMeshWaves) void rt_bin_shadow(const FramePara
       }
       for (int s2 = 0; s2 < 8; ++s2) {
         const int ixc = 2 * ixq + (s2 & 1), iyc = 2 * iyq + ((s2 >> 1) & 1), izc = 2 * izq + (s2 >> 2);
-        if (!occupied(P, 1, ixc, iyc, izc)) continue;
         // (its eight single cells: dx in {2 (s2&1), +1}, ...)
         const unsigned long long sub_bits = 0x0000000000330033ull << (2 * (s2 & 1) + 8 * ((s2 >> 1) & 1) + 32 * (s2 >> 2));
-        if ((open & sub_bits) == 0ull) continue;
-        if (ballot(ok && !cell_clear(centre(ixc, iyc, izc, 2.0f * P.grid_cell), 2.0f * half)) == 0ull) continue;
+        const int n_open = __popcll(open & sub_bits);
+        if (n_open == 0) continue;
+        // (the tile test leaves 12 % of the single cells open: the bound of the 2 x 2 x 2 block is only worth its price where
+        // it can spare three or more of them)
+        if (n_open >= 3 && ballot(ok && !cell_clear(centre(ixc, iyc, izc, 2.0f * P.grid_cell), 2.0f * half)) == 0ull) continue;
         for (int sub = 0; sub < 8; ++sub) {
           const int ix = 2 * ixc + (sub & 1), iy = 2 * iyc + ((sub >> 1) & 1), iz = 2 * izc + (sub >> 2);
           if (((open >> (((iz & 3) << 4) | ((iy & 3) << 2) | (ix & 3))) & 1ull) == 0ull) continue;      // (unoccupied, or the tile test settled it)
-          if (!occupied(P, 0, ix, iy, iz)) continue;
           const unsigned long long m = ballot(ok && !cell_clear(centre(ix, iy, iz, P.grid_cell), half));
           if (m != 0ull && lane == 0)
             atomicOr(&P.world_masks[((size_t)(iz * G + iy) * G + ix) * P.nwords + (t >> 6)], 1ull << (t & 63));
