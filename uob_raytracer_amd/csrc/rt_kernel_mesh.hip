@@ -228,14 +228,11 @@ __global__ __launch_bounds__(64 * kMeshWaves) void rt_bin_primary(const FramePar
   const float4 c4 = P.records[(size_t)3 * n + g];
   const f3 c = xyz(c4), pc = xyz(P.records[(size_t)6 * n + g]), qc = xyz(P.records[(size_t)7 * n + g]);
   const f3 r0 = mk(P.rot[0], P.rot[1], P.rot[2]), r1 = mk(P.rot[4], P.rot[5], P.rot[6]), r2 = mk(P.rot[8], P.rot[9], P.rot[10]);
-  const int cy = blockIdx.y;
-  const int ylo = cy * kScreenCell, yhi = (ylo + kScreenCell - 1) < P.H ? (ylo + kScreenCell - 1) : (P.H - 1);
-  // sub-pixel rectangle of the cell, in the units of primary_ray() (rt_trace.h)
-  const float Ylo = ((float)(ylo * P.aa_y) - P.half_hy) * P.sy;
-  const float Yhi = ((float)(yhi * P.aa_y + P.aa_y - 1) - P.half_hy) * P.sy;
-  const float hy = 0.5f * (Yhi - Ylo);
-  for (int cx = 0; cx < P.scx; ++cx) {
-    const int xlo = cx * kScreenCell, xhi = (xlo + kScreenCell - 1) < P.W ? (xlo + kScreenCell - 1) : (P.W - 1);
+  // does any triangle of the tile stay uncertified for the primary rays through the pixel rectangle [xlo, xhi] x [ylo, yhi]?
+  auto rect_open = [&](int xlo, int xhi, int ylo, int yhi) -> bool {
+    const float Ylo = ((float)(ylo * P.aa_y) - P.half_hy) * P.sy;
+    const float Yhi = ((float)(yhi * P.aa_y + P.aa_y - 1) - P.half_hy) * P.sy;
+    const float hy = 0.5f * (Yhi - Ylo);
     const float Xlo = (float)(xlo * P.aa_x) - P.half_wx;
     const float Xhi = (float)(xhi * P.aa_x + P.aa_x - 1) - P.half_wx;
     const float hx = 0.5f * (Xhi - Xlo);
@@ -245,9 +242,24 @@ __global__ __launch_bounds__(64 * kMeshWaves) void rt_bin_primary(const FramePar
                      1.0001f * (fabsf(r2.x) * hx + fabsf(r2.y) * hy));
     const float dumax = fmaxf(fmaxf(fabsf(duc.x) + eu.x, fabsf(duc.y) + eu.y), fabsf(duc.z) + eu.z);
     const bool clear = (dumax < 1e30f) && primary_clear(duc, eu, dumax, c, c4.w, pc, qc);
-    const unsigned long long m = ballot(ok && !clear);
-    if (m != 0ull && lane == 0)
-      atomicOr(&P.screen_masks[((size_t)cy * P.scx + cx) * P.nwords + (t >> 6)], 1ull << (t & 63));
+    return ballot(ok && !clear) != 0ull;
+  };
+  // blockIdx.y = a row of 4 x 4-cell blocks: a block first (what is clear for a set of rays is clear for every subset — a
+  // tile of a mesh covers a few cells of the thousands), its sixteen cells only where that leaves something open
+  const int cyb = blockIdx.y * 4;
+  for (int cxb = 0; cxb < P.scx; cxb += 4) {
+    const int bx1 = (cxb + 4 < P.scx ? cxb + 4 : P.scx), by1 = (cyb + 4 < P.scy ? cyb + 4 : P.scy);
+    const int pxhi = bx1 * kScreenCell - 1 < P.W - 1 ? bx1 * kScreenCell - 1 : P.W - 1;
+    const int pyhi = by1 * kScreenCell - 1 < P.H - 1 ? by1 * kScreenCell - 1 : P.H - 1;
+    if (!rect_open(cxb * kScreenCell, pxhi, cyb * kScreenCell, pyhi)) continue;
+    for (int cy = cyb; cy < by1; ++cy) {
+      const int ylo = cy * kScreenCell, yhi = (ylo + kScreenCell - 1) < P.H ? (ylo + kScreenCell - 1) : (P.H - 1);
+      for (int cx = cxb; cx < bx1; ++cx) {
+        const int xlo = cx * kScreenCell, xhi = (xlo + kScreenCell - 1) < P.W ? (xlo + kScreenCell - 1) : (P.W - 1);
+        if (rect_open(xlo, xhi, ylo, yhi) && lane == 0)
+          atomicOr(&P.screen_masks[((size_t)cy * P.scx + cx) * P.nwords + (t >> 6)], 1ull << (t & 63));
+      }
+    }
   }
 }
 
@@ -1247,7 +1259,7 @@ void launch_mesh(const FrameParams& P, bool count, bool prof, hipStream_t stream
     hipMemsetAsync(P.world_occ, 0, (size_t)occ_words(P.grid_g) * sizeof(unsigned int), stream);
     const bool fork = aux != nullptr && ev_fork != nullptr && ev_join != nullptr &&
                       hipEventRecord(ev_fork, stream) == hipSuccess && hipStreamWaitEvent(aux, ev_fork, 0) == hipSuccess;
-    hipLaunchKernelGGL(rt_bin_primary, dim3((ntiles + kMeshWaves - 1) / kMeshWaves, P.scy), block, 0, fork ? aux : stream, P);
+    hipLaunchKernelGGL(rt_bin_primary, dim3((ntiles + kMeshWaves - 1) / kMeshWaves, (P.scy + 3) / 4), block, 0, fork ? aux : stream, P);
     if (fork) hipEventRecord(ev_join, aux);
     hipLaunchKernelGGL(rt_bin_occupancy, dim3((P.n + P.nsph + kOccThreads - 1) / kOccThreads), dim3(kOccThreads), (size_t)occ_words(P.grid_g) * sizeof(unsigned int), stream, P);
     hipLaunchKernelGGL(rt_bin_shadow, dim3((ntiles + kMeshWaves - 1) / kMeshWaves, P.grid_g / 4, P.grid_g / 4), block, 0, stream, P);
