@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from uob_raytracer_amd import abi, meshgen, runtime as rt
 n_lon, n_lat, W = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 path = os.path.join(tempfile.mkdtemp(), "m.obj")
-nf = meshgen.write_sphere_obj(path, n_lon, n_lat)
+nf = meshgen.write_cubesphere_obj(path, n_lon) if os.environ.get("CUBE") else meshgen.write_sphere_obj(path, n_lon, n_lat)     # CUBE=1: a cube-sphere of 12 n_lon^2 triangles (no polar slivers)
 scene = rt.Scene.cornell_box() + rt.Scene.load_obj(path)
 cfg = abi.make_config(width=W, height=W, aa_x=1, aa_y=1, shadow_samples=1, spheres=() if os.environ.get("NOSPH", "1") == "1" else abi.REFERENCE_SPHERES)   # configs[4] as bench.py --workload cfg5
 tr = rt.RayTracer(cfg, scene)

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from uob_raytracer_amd import abi, meshgen, runtime as rt
 path = os.path.join(tempfile.mkdtemp(), "m.obj")
-meshgen.write_sphere_obj(path, 250, 201)
+meshgen.write_cubesphere_obj(path, 91) if os.environ.get("CUBE") else meshgen.write_sphere_obj(path, 250, 201)
 scene = rt.Scene.cornell_box() + rt.Scene.load_obj(path)
 W = 2048
 cfg = abi.make_config(width=W, height=W, aa_x=1, aa_y=1, shadow_samples=1, spheres=())

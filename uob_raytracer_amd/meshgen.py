@@ -37,3 +37,37 @@ def write_sphere_obj(path, n_lon=32, n_lat=24, radius=0.13, center=(0.0, 0.25, 0
         for t in faces:
             f.write("f %d %d %d\n" % t)
     return len(faces)
+
+
+def write_cubesphere_obj(path, n=91, radius=0.13, center=(0.0, 0.25, 0.0), bumps=0.15):
+    """The same bumpy sphere from a cube's six n x n grids pushed out to it: 12 n^2 triangles of similar size and shape — no
+    polar slivers (a UV sphere's triangles next to its poles have an aspect of 40:1 at 100 000 triangles).  Wound outward."""
+    verts, index, faces = [], {}, []
+
+    def vid(face, i, j):
+        # cube-surface point of grid node (i, j) of a face, shared along the cube's edges through its rounded coordinates
+        a, b = 2.0 * i / n - 1.0, 2.0 * j / n - 1.0
+        p = [(1.0, a, b), (-1.0, b, a), (b, 1.0, a), (a, -1.0, b), (a, b, 1.0), (b, a, -1.0)][face]
+        key = (round(p[0] * n), round(p[1] * n), round(p[2] * n))
+        if key not in index:
+            ln = math.sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2])
+            d = (p[0] / ln, p[1] / ln, p[2] / ln)
+            th, ph = math.acos(max(-1.0, min(1.0, d[1]))), math.atan2(d[2], d[0])
+            r = radius * (1.0 + bumps * math.sin(5 * ph) * math.sin(4 * th))
+            verts.append((center[0] + r * d[0], center[1] + r * d[1], center[2] + r * d[2]))
+            index[key] = len(verts)
+        return index[key]
+
+    for face in range(6):
+        for i in range(n):
+            for j in range(n):
+                a, b, c, d = vid(face, i, j), vid(face, i + 1, j), vid(face, i, j + 1), vid(face, i + 1, j + 1)
+                faces.append((a, b, d))          # (a, b, d), (a, d, c): counter-clockwise seen from outside on every face
+                faces.append((a, d, c))
+    with open(path, "w") as f:
+        f.write("# synthetic bumpy cube-sphere: %d vertices, %d faces\n" % (len(verts), len(faces)))
+        for v in verts:
+            f.write("v %.7f %.7f %.7f\n" % v)
+        for t in faces:
+            f.write("f %d %d %d\n" % t)
+    return len(faces)
