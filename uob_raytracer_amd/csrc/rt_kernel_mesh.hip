@@ -924,9 +924,27 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
     }
     __syncthreads();
     MESH_STAMP(3)
+    // the world-cell masks of this wave's groups, one 64-tile word at a time (lane g = group g): the tiles come in rising
+    // order, so a word is loaded once per 64 tiles instead of once per tile and group in front of every bound
+    int gm_word = -1;
+    unsigned long long gm_bits = ~0ull;
     auto shadow_tile = [&](int t, const float4* tbase) {
       const float4 *t_v0 = tbase, *t_e1 = tbase + kTile, *t_e2 = tbase + 2 * kTile, *t_c = tbase + 3 * kTile;
       if (litmask == 0ull || task_blocked) return;              // wave-uniform; the barriers are behind us
+      unsigned long long gwant = ~0ull;                          // groups whose own cell names this tile
+      if (task_ok) {
+        if ((t >> 6) != gm_word) {
+          gm_word = t >> 6;
+          unsigned long long v = ~0ull;
+          if (lane < ngroups) {
+            const int cellg = __float_as_int(L.grp[4 * lane + 3].z);
+            if (cellg >= 0 && !(PC(mask_debug) & 2)) v = PC(world_masks)[(size_t)cellg * nwords + gm_word];
+          }
+          gm_bits = v;
+        }
+        gwant = ballot(lane < ngroups && ((gm_bits >> (t & 63)) & 1ull) != 0ull);
+        if (gwant == 0ull) return;                               // (the tile is in the workgroup's union for another wave's sake)
+      }
       const int nc = (n - t * kTile) < kTile ? (n - t * kTile) : kTile;
       const unsigned long long casts = ballot(lane < nc && t_v0[lane].w != -1.0f);    // glass casts no shadow, :247
       unsigned long long K = casts;
@@ -946,9 +964,7 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
           // the group's own cell has certified this whole tile clear (rt_bin_shadow): nothing to bound, nothing to test.
           // (The workgroup visits the union of its 256 points' cells' tiles; a task that straddles a silhouette holds
           // six groups, and most tiles of the union matter to one of them.)
-          const int gcell = __builtin_amdgcn_readfirstlane(__float_as_int(g3.z));
-          if (gcell >= 0 && !(PC(mask_debug) & 2) &&
-              ((PC(world_masks)[(size_t)gcell * nwords + (t >> 6)] >> (t & 63)) & 1ull) == 0ull) continue;
+          if (((gwant >> g) & 1ull) == 0ull) continue;
           unsigned long long Kg = casts;
           if (g0.w < 1e30f && g1.w < 1e30f) {
             const Bound tb = light_bundle_bound(T1, light, mk(g0.x, g0.y, g0.z), g0.w, mk(g1.x, g1.y, g1.z), g1.w, g2.z, g2.x, g2.y,
