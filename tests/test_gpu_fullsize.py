@@ -94,6 +94,20 @@ def plain_box_pixels(cfg):
     return _PLAIN[key]
 
 
+def test_configs4_masks_stay_sparse(box_and_big_mesh):
+    """How much the bounds can certify shows in the per-frame shadow-ray masks (rt_debug_world_masks): of the 1 563 tiles an
+    occupied world cell names 34 on average (49 before the |u| > 1 clause, 52 before the tile-level certificate).  A guard
+    against a bound silently losing a clause: frames would stay identical, only slower."""
+    tr = rt.RayTracer(abi.make_config(**CFG5["cfg5_1spp_1shadow"]), box_and_big_mesh)
+    tr.render(rt.rotation_matrix(*ROT0), DEFAULT_CAM, DEFAULT_LIGHT, focal_for(tr.cfg))
+    masks = tr.world_masks()
+    tr.close()
+    per_cell = np.unpackbits(masks.view(np.uint8), axis=-1).sum(-1)
+    occupied = per_cell[per_cell > 0]
+    assert 5000 < occupied.size < 12000
+    assert occupied.mean() < 40.0, occupied.mean()
+
+
 @pytest.mark.parametrize("flags", [0, abi.RT_FLAG_NO_CULL])
 def test_configs2_mirror_wall_1080p(flags, scene, oracle):
     """configs[2] as BASELINE.json words it: glass sphere + mirror wall, 1920x1080, 4xAA, depth 5 (back wall -> mirror,
