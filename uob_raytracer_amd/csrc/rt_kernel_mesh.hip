@@ -35,7 +35,15 @@ constexpr int kBatch = 4;                   // candidate tiles staged per barrie
 constexpr int kSlot = 4 * kTile;            // float4 per staged tile
 constexpr int kMeshWaves = 4;               // waves (= tasks) per workgroup sharing a tile
 constexpr int kDirectSamples = 2;           // up to this many, level 2 is skipped as well (the test is cheaper than its bound)
-constexpr int kPointSamples = 8;            // up to this many shadow samples, level 3 runs lane = surface point
+// Up to this many shadow samples level 3 runs lane = surface point (every lane tests its own point's samples one after the other)
+// instead of lane = sample (two points per pass, NS of 64 lanes busy).  Measured (1024^2, reference constants otherwise): box +
+// 226-triangle mesh, 10 samples: 0.70 ms with the limit at 8, 0.585 at 16; box + 4 680 triangles, 16 samples: 7.98 / 5.94;
+// 10 samples at 2048^2: 10.2 / 5.07; at 24 and 32 samples the two forms are level (0.73 / 0.72, 8.11 / 8.45), at 64 lane =
+// point is 1.7 x slower.
+#ifndef RT_MESH_POINT_SAMPLES
+#define RT_MESH_POINT_SAMPLES 16
+#endif
+constexpr int kPointSamples = RT_MESH_POINT_SAMPLES;
 constexpr int kScreenCell = 32;             // pixels per side of a screen cell of the primary-ray tile masks
 constexpr int kScreenCellLog = 5;
 
