@@ -5,18 +5,17 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from uob_raytracer_amd import abi, meshgen, runtime as rt
 path = os.path.join(tempfile.mkdtemp(), "m.obj")
-meshgen.write_sphere_obj(path, int(os.environ.get("LON", "10")), int(os.environ.get("LAT", "11")))          # LON / LAT: other mesh sizes
+meshgen.write_sphere_obj(path, 10, 11)
 scene = rt.Scene.cornell_box() + rt.Scene.load_obj(path)
 rot, cam, light = rt.rotation_matrix(0, 0), [0, 0, -3.2], [0, -0.5, -0.7]
 names = ["0 job + task set-up", "1 primary tiles", "2 primary load / hit", "3 shadow set-up", "4 tile load + barrier", "5 level 1", "6 level 2", "7 level 3 + rest"]
 os.environ["UOB_RT_PHASE_PROFILE"] = "1"
-KW = dict(shadow_samples=int(os.environ.get("S", "10")), width=int(os.environ.get("W", "1024")), height=int(os.environ.get("W", "1024")))
-tr = rt.RayTracer(abi.make_config(**KW), scene)
-v = list(tr.count_executed(rot, cam, light, 2200.0 * KW["width"] / 1024).values())
+tr = rt.RayTracer(abi.make_config(), scene)
+v = list(tr.count_executed(rot, cam, light, 2200.0).values())
 tot = sum(v)
 for n, x in zip(names, v):
     print("%-24s %5.1f %%" % (n, 100.0 * x / tot))
 tr.close()
 del os.environ["UOB_RT_PHASE_PROFILE"]
-tr = rt.RayTracer(abi.make_config(**KW), scene)
-print(tr.count_executed(rot, cam, light, 2200.0 * KW["width"] / 1024))
+tr = rt.RayTracer(abi.make_config(), scene)
+print(tr.count_executed(rot, cam, light, 2200.0))

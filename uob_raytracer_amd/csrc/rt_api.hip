@@ -70,7 +70,6 @@ using namespace uobrt;
     }                                                                                   \
   } while (0)
 
-constexpr size_t kMeshOrderPerBlock = 17;  // order-list entries per block: every block split into 4 sub-blocks x 4 tasks (2x2 AA, the tests' all-cooperative mode) or an eighth of them into 4 x 16; rt_mesh_order falls back to whole sub-blocks where that is not enough
 constexpr int kWorldGrid = 32;       // world cells per axis of the mesh kernel's shadow-ray tile masks
 
 // Tuning knobs, read from the environment ONCE per context (rt_init); 0 / false = the built-in choice
@@ -552,7 +551,7 @@ int rt_init(const rt_config* cfg, const float* vertices4, const float* normals4,
     if (!c->tune.plain_order) {
       const size_t jobs = (size_t)((cfg->width + 15) / 16) * (size_t)((c->owned_rows + 15) / 16);
       // order list: up to four entries per block, + its length in the word behind it
-      if (hipMalloc(&c->d_mesh_cost, (jobs ? jobs : 1) * 4) != hipSuccess || hipMalloc(&c->d_mesh_order, (kMeshOrderPerBlock * (jobs ? jobs : 1) + 1) * 4) != hipSuccess) {
+      if (hipMalloc(&c->d_mesh_cost, (jobs ? jobs : 1) * 4) != hipSuccess || hipMalloc(&c->d_mesh_order, (4 * (jobs ? jobs : 1) + 1) * 4) != hipSuccess) {
         set_error("hipMalloc failed: %s", hipGetErrorString(hipGetLastError())); return fail(RT_E_NOMEM);
       }
     }
@@ -744,8 +743,7 @@ static int launch_frame(rt_ctx* c, const float rot[12], const float cam[3], cons
     if (c->d_mesh_cost) {                   // last frame's expensive blocks first; this frame's costs make the next order
       P.mesh_order = c->mesh_order_valid ? c->d_mesh_order : nullptr;
       P.mesh_cost = c->d_mesh_cost; P.mesh_order_out = c->d_mesh_order;
-      P.mesh_order_cap = (uint32_t)(kMeshOrderPerBlock * (size_t)((c->cfg.width + 15) / 16) * (size_t)((c->owned_rows + 15) / 16));
-      P.mesh_queue_len = c->d_mesh_order + P.mesh_order_cap;
+      P.mesh_queue_len = c->d_mesh_order + 4 * (size_t)((c->cfg.width + 15) / 16) * (size_t)((c->owned_rows + 15) / 16);
       c->mesh_order_valid = true;
     }
     launch_stage_records(P, stream);        // per frame: the records hold camera-dependent terms

@@ -96,8 +96,7 @@ struct FrameParams {
   const unsigned int* mesh_order;   // job order of this frame (nullptr: plain order)
   unsigned int* mesh_cost;          // per block: s_memtime ticks it took this frame (nullptr: not recorded)
   unsigned int* mesh_order_out;     // next frame's order, written by rt_mesh_order after the frame
-  unsigned int* mesh_queue_len;     // its length (a very expensive block is entered as four cooperative sub-block jobs, each split by task)
-  uint32_t mesh_order_cap;          // entries the order list can hold
+  unsigned int* mesh_queue_len;     // its length (a very expensive block is entered as four cooperative sub-block jobs)
   int32_t mesh_blocks;              // workgroups the device holds at once
   const int* orig;        // mesh kernel: original index of every (reordered) triangle; nullptr = the order is the original
   const float4* tile_box; // mesh kernel: per 64-triangle tile, 3 float4: box lo.xyz | eta, box hi.xyz | sigma, normal-cone axis | chi (rt_api.hip)

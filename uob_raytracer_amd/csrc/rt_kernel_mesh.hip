@@ -517,19 +517,15 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
   if (tid == 0) s_job = (int)atomicAdd(PC(job_counter), 1u);
   __syncthreads();
   if (s_job >= n_queue) break;                         // the counter only grows: every workgroup gets here
-  // An entry of the order list is (block << 10) | (task + 1) << 3 | (cooperative << 2) | sub-block.  A block that was VERY expensive in the
+  // An entry of the order list is (block << 3) | (cooperative << 2) | sub-block.  A block that was VERY expensive in the
   // previous frame comes as four cooperative entries, one per 8x8 sub-block: the four waves then work on the SAME 64
   // pixels and share the TILES (of every staged batch of four, wave w takes tile w), merging what they found per lane
   // through LDS — closest hit: smallest (t, original index); shadows: OR of the blocked-sample masks.  The longest
   // unit of work is then a quarter of a sub-block's tiles instead of a whole block's.
-  // (bits 3..9: 0 = every task of the sub-block, k + 1 = its task k alone — a cooperative sub-block with several tasks, 2x2 AA and
-  // more, comes as one entry per task: its bounce rounds and its penumbra make ONE task of a block on a sphere's rim a
-  // millisecond, and the frame ends when the longest entry does)
-  const unsigned int entry = PC(mesh_order) != nullptr ? PC(mesh_order)[s_job] : ((unsigned int)s_job << 10);
-  const int job = (int)(entry >> 10);
+  const unsigned int entry = PC(mesh_order) != nullptr ? PC(mesh_order)[s_job] : ((unsigned int)s_job << 3);
+  const int job = (int)(entry >> 3);
   const bool coop = (entry & 4u) != 0u;
   const int coop_q = (int)(entry & 3u);
-  const int task_sel = (int)((entry >> 3) & 127u) - 1;
   const unsigned long long job_t0 = (COUNT || PC(mesh_cost) != nullptr) ? __builtin_amdgcn_s_memtime() : 0ull;
   const int job_y = job / wgx_n, job_x = job - job_y * wgx_n;
   // without an order list: rows from the middle of the frame outwards (the last to start are the top and bottom ones)
@@ -598,7 +594,7 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
   };
 
   f3 outc = mk(0.f, 0.f, 0.f);
-  for (int k = (task_sel >= 0 ? task_sel : 0); k < (task_sel >= 0 ? task_sel + 1 : ntask); ++k) {
+  for (int k = 0; k < ntask; ++k) {
     // ---- phase 1: primary rays over all tiles -------------------------------------------------------
     const int p = (AA_X && AA_Y) ? lane / (AA_X * AA_Y ? AA_X * AA_Y : 1) : (lane * P.aa_magic) >> 16;    // pixel of this lane within the task (lane / aa)
     const int a = lane - p * aa;                // AA sample index dy*rx+dx, kernels.cl:395
@@ -1161,12 +1157,11 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
     }
   }
   MESH_STAMP(7)
-  if (COUNT) xw[7] += task_sel >= 0 ? 1 : ntask;
+  if (COUNT) xw[7] += ntask;
   {
     const int x = B.x0 + (lane & 7);
     const int lr = B.lr0 + (lane >> 3);
-    const int my_task = (zorder_of(lane & 7, lane >> 3) * pt_magic) >> 16;               // the task that rendered this lane's pixel
-    if (!COUNT && !PROF && (!coop || wave == 0) && (task_sel < 0 || my_task == task_sel) && lr < P.owned_rows && x < P.W) {      // the counting pass has no framebuffer
+    if (!COUNT && !PROF && (!coop || wave == 0) && lr < P.owned_rows && x < P.W) {      // the counting pass has no framebuffer
       const f3 c = mk(div_count(outc.x, aa, inv_aa), div_count(outc.y, aa, inv_aa), div_count(outc.z, aa, inv_aa));
       const size_t o = (size_t)(PC(out_global) ? band_global_row_cold(P, lr) : lr) * P.W + x;
       PC(out_argb)[o] = pack_argb(c);
@@ -1192,11 +1187,12 @@ __global__ __launch_bounds__(64 * kMeshWaves, RT_MESH_MIN_BLOCKS) void rt_draw_m
 // order is whatever the atomics make it — no pixel depends on it); a block that cost more than 8x the mean (and more than
 // a quarter of the dearest) is entered as four cooperative sub-block jobs.  One workgroup.
 __global__ __launch_bounds__(1024) void rt_mesh_order(const unsigned int* cost, unsigned int* order, unsigned int* queue_len, int n_jobs,
-                                                      int coop_all, int ntask, unsigned int cap) {
-  __shared__ unsigned int smax, hist[64], base[64], s_total;
+                                                      int coop_all) {
+  __shared__ unsigned int smax, hist[64], base[64];
   __shared__ unsigned long long ssum;
   const int tid = threadIdx.x;
   if (tid == 0) { smax = 0u; ssum = 0ull; }
+  if (tid < 64) hist[tid] = 0u;
   __syncthreads();
   unsigned int m = 0u;
   unsigned long long sum = 0ull;
@@ -1208,35 +1204,22 @@ __global__ __launch_bounds__(1024) void rt_mesh_order(const unsigned int* cost, 
   const unsigned long long mean8 = 8ull * (ssum / (unsigned long long)(n_jobs > 0 ? n_jobs : 1));
   // coop_all (UOB_RT_MESH_COOP=1, tests): every block comes back cooperative
   const unsigned long long heavy = coop_all ? 0ull : (mean8 > (unsigned long long)smax / 4ull ? mean8 : (unsigned long long)smax / 4ull);
-  // a cooperative sub-block comes as one entry per task (up to 16 tasks: 2x2 ... 4x4 AA) — unless the list cannot hold that many
-  unsigned int per_block = 4u * (unsigned int)(ntask >= 2 && ntask <= 16 ? ntask : 1);
-  for (int attempt = 0; attempt < 2; ++attempt) {
-    if (tid < 64) hist[tid] = 0u;
-    __syncthreads();
-    for (int i = tid; i < n_jobs; i += 1024)
-      atomicAdd(&hist[63 - (int)((unsigned long long)cost[i] * 64ull / scale)], (unsigned long long)cost[i] > heavy ? per_block : 1u);
-    __syncthreads();
-    if (tid == 0) {
-      unsigned int at = 0u;
-      for (int b = 0; b < 64; ++b) { base[b] = at; at += hist[b]; }
-      s_total = at;
-    }
-    __syncthreads();
-    if (s_total <= cap || per_block == 4u) break;
-    per_block = 4u;                                              // too many entries: whole sub-blocks
-    __syncthreads();
+  for (int i = tid; i < n_jobs; i += 1024)
+    atomicAdd(&hist[63 - (int)((unsigned long long)cost[i] * 64ull / scale)], (unsigned long long)cost[i] > heavy ? 4u : 1u);
+  __syncthreads();
+  if (tid == 0) {
+    unsigned int at = 0u;
+    for (int b = 0; b < 64; ++b) { base[b] = at; at += hist[b]; }
+    queue_len[0] = at;
   }
-  if (tid == 0) queue_len[0] = s_total;
-  const unsigned int nts = per_block / 4u;
+  __syncthreads();
   for (int i = tid; i < n_jobs; i += 1024) {
     const int b = 63 - (int)((unsigned long long)cost[i] * 64ull / scale);
     if ((unsigned long long)cost[i] > heavy) {
-      const unsigned int at = atomicAdd(&base[b], per_block);
-      for (unsigned int k = 0; k < nts; ++k)
-        for (unsigned int q = 0; q < 4u; ++q)
-          order[at + 4u * k + q] = ((unsigned int)i << 10) | ((nts > 1u ? k + 1u : 0u) << 3) | 4u | q;
+      const unsigned int at = atomicAdd(&base[b], 4u);
+      for (unsigned int q = 0; q < 4u; ++q) order[at + q] = ((unsigned int)i << 3) | 4u | q;
     } else {
-      order[atomicAdd(&base[b], 1u)] = (unsigned int)i << 10;
+      order[atomicAdd(&base[b], 1u)] = (unsigned int)i << 3;
     }
   }
 }
@@ -1307,7 +1290,6 @@ void launch_mesh(const FrameParams& P, bool count, bool prof, hipStream_t stream
     if (fork) hipStreamWaitEvent(stream, ev_join, 0);
   }
   const int n_jobs = ((P.W + 15) / 16) * ((P.owned_rows + 15) / 16);
-  const int order_tasks = (64 + (64 / (P.aa_x * P.aa_y)) - 1) / (64 / (P.aa_x * P.aa_y));      // 64-ray tasks of an 8x8 sub-block (aa <= 64 here)
   const int resident = P.mesh_blocks > 0 ? P.mesh_blocks : 256 * RT_MESH_MIN_BLOCKS;
   const dim3 grid(n_jobs < resident ? (n_jobs > 0 ? n_jobs : 1) : resident);
   hipMemsetAsync(P.job_counter, 0, sizeof(unsigned int), stream);
@@ -1317,8 +1299,7 @@ void launch_mesh(const FrameParams& P, bool count, bool prof, hipStream_t stream
   if (!count && P.mesh_order == nullptr && P.mesh_cost != nullptr && P.mesh_order_out != nullptr && P.screen_masks != nullptr &&
       !(P.mask_debug & 16)) {                           // the context's first frame: order it by the guess (mask_debug 16: do not)
     hipLaunchKernelGGL(rt_mesh_estimate, dim3((n_jobs + 255) / 256), dim3(256), 0, stream, P, P.mesh_cost, n_jobs);
-    hipLaunchKernelGGL(rt_mesh_order, dim3(1), dim3(1024), 0, stream, P.mesh_cost, P.mesh_order_out, P.mesh_queue_len, n_jobs, (P.mask_debug & 8) ? 1 : 0,
-                       order_tasks, (unsigned int)P.mesh_order_cap);
+    hipLaunchKernelGGL(rt_mesh_order, dim3(1), dim3(1024), 0, stream, P.mesh_cost, P.mesh_order_out, P.mesh_queue_len, n_jobs, (P.mask_debug & 8) ? 1 : 0);
     Q.mesh_order = P.mesh_order_out;
   }
   if (!count && P.mesh_cost != nullptr) hipMemsetAsync(P.mesh_cost, 0, (size_t)n_jobs * 4, stream);
@@ -1328,8 +1309,7 @@ void launch_mesh(const FrameParams& P, bool count, bool prof, hipStream_t stream
   // against 7.87 ms generic; this kernel is bound by the tile stream through LDS and its barriers, not by instruction issue)
   else hipLaunchKernelGGL((rt_draw_mesh<false>), grid, block, lds_bytes, stream, Q);
   if (!count && P.mesh_cost != nullptr && P.mesh_order_out != nullptr)
-    hipLaunchKernelGGL(rt_mesh_order, dim3(1), dim3(1024), 0, stream, P.mesh_cost, P.mesh_order_out, P.mesh_queue_len, n_jobs, (P.mask_debug & 8) ? 1 : 0,
-                       order_tasks, (unsigned int)P.mesh_order_cap);
+    hipLaunchKernelGGL(rt_mesh_order, dim3(1), dim3(1024), 0, stream, P.mesh_cost, P.mesh_order_out, P.mesh_queue_len, n_jobs, (P.mask_debug & 8) ? 1 : 0);
 }
 
 int mesh_blocks_per_cu() { return RT_MESH_MIN_BLOCKS; }
